@@ -1,0 +1,114 @@
+/* lightglue_amd — C ABI of the MI355X-native LightGlue matcher forward path.
+ *
+ * The reference (cvg/LightGlue) has no FFI / plugin boundary: its matcher is the Python class
+ * `lightglue.LightGlue` (lightglue/lightglue.py:321, exported at lightglue/__init__.py:4).  This
+ * header is the boundary a binding of that class's hot path would sit on: one opaque engine that
+ * replaces `LightGlue.__init__` weight handling (lightglue.py:376-437) and `LightGlue._forward`
+ * (lightglue.py:483-629).  Plain pointers and sizes only; every data pointer is a DEVICE pointer
+ * owned by the caller unless stated otherwise; kernels are enqueued on the caller's HIP stream.
+ * Python binding: lightglue_amd/_cabi.py (ctypes).  See INTEGRATION.md.
+ */
+#ifndef LIGHTGLUE_AMD_H
+#define LIGHTGLUE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Operand precision of the matrix-core contractions (accumulation is always fp32). */
+enum {
+    LG_PREC_F32 = 0,    /* v_mfma_f32_16x16x4_f32: exact fp32 products (parity anchor)            */
+    LG_PREC_BF16 = 1,   /* v_mfma_f32_16x16x32_bf16                                                */
+    LG_PREC_F16 = 2,    /* v_mfma_f32_16x16x32_f16                                                 */
+    LG_PREC_BF16X3 = 3  /* split bf16 (hi+lo, 3 MFMAs) for linear layers / similarity; attention
+                           runs in f16 like the reference's GPU path (lightglue.py:119)          */
+};
+
+#define LG_OK 0
+#define LG_ERR_INVALID 1   /* bad argument (the Python shim raises AssertionError/ValueError)      */
+#define LG_ERR_HIP 2       /* a HIP runtime call failed; see lg_last_error()                       */
+#define LG_ERR_STATE 3     /* call order violated (e.g. forward before weights were finalised)     */
+
+/* Mirrors LightGlue.default_conf (lightglue.py:322-335) for the keys the forward path reads. */
+typedef struct lg_config {
+    int32_t input_dim;          /* 256 SuperPoint, 128 DISK/ALIKED/SIFT (lightglue.py:351-374)   */
+    int32_t descriptor_dim;     /* must be 256                                                    */
+    int32_t n_layers;           /* 9                                                              */
+    int32_t num_heads;          /* must be 4 (head_dim 64)                                        */
+    int32_t add_scale_ori;      /* 0/1: 4-D positional input (lightglue.py:495-501)               */
+    double depth_confidence;    /* early stop, <= 0 disables (lightglue.py:528)                   */
+    double width_confidence;    /* point pruning, <= 0 disables (lightglue.py:529)                */
+    double filter_threshold;    /* lightglue.py:592                                               */
+    int32_t pruning_min_kpts;   /* resolved LightGlue.pruning_min_kpts() (lightglue.py:658-662)   */
+    int32_t precision;          /* LG_PREC_*                                                      */
+    int32_t attn_precision;     /* LG_PREC_F32/BF16/F16 or -1 = derive from `precision`           */
+} lg_config;
+
+typedef struct lg_engine lg_engine;
+
+/* Everything one forward reads and writes.  Inputs are dense [B][n][..] fp32, exactly the tensors of
+ * the reference's input dict (lightglue.py:460-468); outputs are the fixed-shape tensors of its output
+ * dict (lightglue.py:619-629) in int32 (the Python shim widens to int64) plus a device-built compact
+ * match list replacing the per-pair torch.where loop (lightglue.py:593-602). */
+#define LG_FLAG_NO_PRUNING 1u /* skip point pruning for this call: the reference's padded/compiled
+                                 path does the same (lightglue.py:529 `and not do_compile`)        */
+
+typedef struct lg_forward_io {
+    int32_t batch, n0, n1;
+    uint32_t flags;                        /* LG_FLAG_*                                           */
+    const float *kpts0, *kpts1;            /* [B][n][2] pixel (x, y)                              */
+    const float *desc0, *desc1;            /* [B][n][input_dim]                                   */
+    const float *size0, *size1;            /* [B][2] (w, h) or NULL -> bounding-box normalisation */
+    const float *scales0, *oris0, *scales1, *oris1; /* [B][n] iff add_scale_ori, else NULL        */
+    int32_t *matches0, *matches1;          /* [B][n0], [B][n1]; -1 = unmatched                    */
+    float *scores0, *scores1;              /* [B][n0], [B][n1]                                    */
+    int32_t *stop;                         /* [B] number of layers executed per pair              */
+    int32_t *prune0, *prune1;              /* [B][n] layer counters; required iff pruning enabled */
+    int32_t *matches;                      /* [B][min(n0,n1)][2] sorted by index0                 */
+    float *match_scores;                   /* [B][min(n0,n1)]                                     */
+    int32_t *n_matches;                    /* [B]                                                 */
+} lg_forward_io;
+
+/* Last error message of the calling thread (never NULL). */
+const char* lg_last_error(void);
+/* Library / ABI version string. */
+const char* lg_version(void);
+
+/* Create an engine on the current HIP device.  Replaces the module construction of
+ * LightGlue.__init__ (lightglue.py:388-413). */
+int lg_engine_create(const lg_config* cfg, lg_engine** out);
+void lg_engine_destroy(lg_engine* e);
+
+/* Stage one state-dict tensor (HOST fp32 pointer, row-major) under its reference name
+ * (e.g. "transformers.3.self_attn.Wqkv.weight"; names/shapes: SURVEY.md §8a, lightglue.py:388-407).
+ * Replaces load_state_dict (lightglue.py:421/434). */
+int lg_engine_set_weight(lg_engine* e, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
+/* Re-pack all staged tensors into kernel layouts / operand precision and upload them. */
+int lg_engine_finalize_weights(lg_engine* e);
+
+/* Pre-size the device workspace (otherwise grown on demand inside forward, which synchronises). */
+int lg_engine_reserve(lg_engine* e, int32_t max_batch, int32_t max_n0, int32_t max_n1);
+
+/* Enqueue one forward (lightglue.py:483-629) on `hip_stream` (a hipStream_t, NULL = default stream).
+ * Asynchronous: no host synchronisation when the workspace is already large enough. */
+int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream);
+
+/* ---- test / profiling taps (not used by the product path) ---- */
+/* Stop the next forwards after pipeline step `step` (-1 = run everything).  Step numbering:
+ * 0 = prep (+input projection); 1 + 12*layer + k, k = 0 self-QKV, 1 self-attention, 2 out_proj,
+ * 3 ffn.0, 4 LayerNorm+GELU, 5 ffn.3+residual, 6 cross-QK/V, 7 cross-attention, 8 to_out, 9 ffn.0,
+ * 10 LayerNorm+GELU, 11 ffn.3+residual. */
+int lg_engine_debug_stop_after(lg_engine* e, int32_t step);
+/* Copy an internal buffer to host (synchronises the device).  Names: X CTX MSG H1 G Q K VT COS SIN MD
+ * SIM LS CONF MSCORE LSE_R LSE_C IND LEN FINAL_LAYER.  *nbytes_out receives the buffer's byte size;
+ * at most max_bytes are copied. */
+int lg_engine_debug_read(lg_engine* e, const char* name, void* host_dst, int64_t max_bytes, int64_t* nbytes_out);
+/* Row capacities chosen for the last forward (multiples of 128) -> global row = pair*(cap0+cap1) + image*cap0 + r */
+int lg_engine_debug_caps(lg_engine* e, int32_t* cap0, int32_t* cap1);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIGHTGLUE_AMD_H */

@@ -1,0 +1,12 @@
+"""lightglue_amd — MI355X-native (gfx950) LightGlue matcher forward path.
+
+Drop-in for the hot path of cvg/LightGlue's ``lightglue.LightGlue`` (reference
+``lightglue/__init__.py:4``): same constructor, same ``forward({'image0','image1'})`` dict API, all
+arithmetic in hand-written HIP kernels behind the C ABI of ``include/lightglue_amd.h``.
+Feature extractors, image I/O and visualisation are out of scope.
+"""
+from .lightglue import LightGlue  # noqa: F401
+from .parallel import PairShardedMatcher, shard_range  # noqa: F401
+
+__all__ = ["LightGlue", "PairShardedMatcher", "shard_range"]
+__version__ = "0.1.0"

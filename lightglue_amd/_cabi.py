@@ -1,0 +1,93 @@
+"""ctypes binding of the C ABI declared in ``include/lightglue_amd.h``.
+
+The shared library ``liblightglue_amd.so`` is built in-tree by ``lightglue_amd/csrc/Makefile``
+(``__graft_entry__.build()``).  There is NO fallback: if the library is missing or fails to load,
+``load()`` raises, and so does every product entry point that needs it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "liblightglue_amd.so"
+
+LG_PREC = {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3}
+LG_OK, LG_ERR_INVALID, LG_ERR_HIP, LG_ERR_STATE = 0, 1, 2, 3
+LG_FLAG_NO_PRUNING = 1
+
+# every symbol include/lightglue_amd.h declares (tests check the library exports all of them)
+EXPORTED_SYMBOLS = (
+    "lg_last_error", "lg_version", "lg_engine_create", "lg_engine_destroy", "lg_engine_set_weight",
+    "lg_engine_finalize_weights", "lg_engine_reserve", "lg_engine_forward",
+    "lg_engine_debug_stop_after", "lg_engine_debug_read", "lg_engine_debug_caps",
+)
+
+
+class LgConfig(C.Structure):
+    _fields_ = [
+        ("input_dim", C.c_int32), ("descriptor_dim", C.c_int32), ("n_layers", C.c_int32), ("num_heads", C.c_int32),
+        ("add_scale_ori", C.c_int32),
+        ("depth_confidence", C.c_double), ("width_confidence", C.c_double), ("filter_threshold", C.c_double),
+        ("pruning_min_kpts", C.c_int32), ("precision", C.c_int32), ("attn_precision", C.c_int32),
+    ]
+
+
+_fp = C.c_void_p  # device pointers travel as integers
+
+
+class LgForwardIO(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("n0", C.c_int32), ("n1", C.c_int32), ("flags", C.c_uint32),
+        ("kpts0", _fp), ("kpts1", _fp), ("desc0", _fp), ("desc1", _fp), ("size0", _fp), ("size1", _fp),
+        ("scales0", _fp), ("oris0", _fp), ("scales1", _fp), ("oris1", _fp),
+        ("matches0", _fp), ("matches1", _fp), ("scores0", _fp), ("scores1", _fp), ("stop", _fp),
+        ("prune0", _fp), ("prune1", _fp), ("matches", _fp), ("match_scores", _fp), ("n_matches", _fp),
+    ]
+
+
+class LightGlueAmdError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def library_path() -> Path:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once).  Raises if it has not been built — never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise LightGlueAmdError(
+            f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C {_LIB_PATH.parent / 'csrc'}`; lightglue_amd has no CPU / PyTorch fallback.")
+    lib = C.CDLL(os.fspath(_LIB_PATH))
+    lib.lg_last_error.restype = C.c_char_p
+    lib.lg_version.restype = C.c_char_p
+    lib.lg_engine_create.argtypes = [C.POINTER(LgConfig), C.POINTER(C.c_void_p)]
+    lib.lg_engine_destroy.argtypes = [C.c_void_p]
+    lib.lg_engine_destroy.restype = None
+    lib.lg_engine_set_weight.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]
+    lib.lg_engine_finalize_weights.argtypes = [C.c_void_p]
+    lib.lg_engine_reserve.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    lib.lg_engine_forward.argtypes = [C.c_void_p, C.POINTER(LgForwardIO), C.c_void_p]
+    lib.lg_engine_debug_stop_after.argtypes = [C.c_void_p, C.c_int32]
+    lib.lg_engine_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    lib.lg_engine_debug_caps.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    """Map C error codes to the exception types the reference raises."""
+    if rc == LG_OK:
+        return
+    msg = load().lg_last_error().decode()
+    if rc == LG_ERR_INVALID:
+        raise AssertionError(msg)
+    raise LightGlueAmdError(f"lightglue_amd error {rc}: {msg}")

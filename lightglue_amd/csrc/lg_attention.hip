@@ -1,0 +1,231 @@
+// lightglue_amd — flash-style attention for the matcher (ref lightglue.py:113-137 Attention,
+// used by SelfBlock :170 and both directions of CrossBlock :211-214 / :216-223).
+//   head_dim 64, 4 heads, non-causal, q_len != kv_len (cross), ragged per-segment lengths.
+//
+// Workgroup = 4 waves = 128 query rows of one (segment, head); K and V^T tiles of 64 keys are
+// staged through LDS (register hop, next tile's loads in flight during the MFMAs) and shared by
+// the 4 waves.  Each wave owns 32 query rows (two 16-row MFMA tiles).
+//
+// "Swapped" formulation (guide T12 idea, 16x16 tiles): S^T = K Q^T and O^T = V^T P^T, so that a
+// query row lives in ONE lane column (lane & 15): the online-softmax max/sum run over a lane's own
+// registers plus two cross-lane steps (lane groups g = 0..3), the rescale factor is a per-lane
+// scalar, and P^T leaves the S^T accumulators already in B-operand order for the PV MFMA:
+//   S^T acc[kt][qt][r] <-> key = 16*kt + 4*g + r, query = 16*qt + (lane & 15)
+//   16-bit PV chunk tp: B element j of lane group g <-> key 32*tp + 16*(j>>2) + 4*g + (j&3)
+//   f32    PV chunk kt: B element i                <-> key 16*kt + 4*g + i
+// V is produced TRANSPOSED by the projection GEMM ([head][d][row]) so the matching A operand is a
+// pair of 8-byte (16-bit) or one 16-byte (f32) contiguous LDS reads.
+// The S matrix never touches HBM.  Softmax runs in fp32 with exp2 and a folded log2(e)/sqrt(64).
+#include "lg_kernels.h"
+
+namespace lg {
+
+constexpr int ABM = 128, ABK = 64, ATHREADS = 256;
+
+template <class Tag>
+__device__ __forceinline__ u32x4 mask_tail(u32x4 v, int nvalid) {  // keep the first nvalid elements of the chunk
+    constexpr int EPC = Tag::EPC;
+    if (nvalid >= EPC) return v;
+    if (nvalid <= 0) return u32x4{0u, 0u, 0u, 0u};
+    if constexpr (EPC == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i >= nvalid) v[i] = 0u;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (2 * i >= nvalid) v[i] = 0u;
+            else if (2 * i + 1 >= nvalid) v[i] &= 0xFFFFu;
+        }
+    }
+    return v;
+}
+
+template <class Tag>
+__global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
+    typedef typename Tag::elem T;
+    constexpr int EPC = Tag::EPC;
+    constexpr int ROWB = 64 * (int)sizeof(T);     // bytes per LDS tile row (128 or 256)
+    constexpr int SLOTS = ROWB / 16;              // 16-byte slots per row
+    constexpr int NC = 64 / (4 * EPC);            // chunks along a 64-long contraction (2 or 4)
+    constexpr int NCT = 64 * SLOTS / ATHREADS;    // staged chunks per thread per tile (2 or 4)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* smK = smem;
+    char* smV = smem + 64 * ROWB;
+
+    const TileLoc t = locate_tile(a.rs, blockIdx.x, ABM);
+    const int qlen = a.rs.len[t.seg];
+    if (t.r0 >= qlen) return;
+    if (a.rs.active && !a.rs.active[t.pair]) return;
+    const int head = blockIdx.y;
+    const int kvseg = a.cross ? (t.seg ^ 1) : t.seg;
+    const int kvlen = a.rs.len[kvseg];
+    const long long kvbase = seg_row_base(a.rs, kvseg);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, g = lane >> 4;
+    const long long R = a.R;
+
+    const T* Q = static_cast<const T*>(a.q);
+    const T* Kp = static_cast<const T*>(a.cross ? a.q : a.k);
+    const T* Vt = static_cast<const T*>(a.vt);
+
+    if (kvlen == 0) {  // ref :114-115: empty key set -> zeros
+        for (int i = tid; i < ABM * 16; i += ATHREADS) {
+            const int row = i >> 4, c4 = i & 15;
+            if (t.r0 + row < qlen) *reinterpret_cast<f32x4*>(a.ctx + (t.grow0 + row) * 256LL + head * 64 + c4 * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
+
+    // Q fragments (B operand of S^T = K Q^T): lane supplies query column lr, k-slots of group g
+    u32x4 qf[2][NC];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const long long grow = t.grow0 + wave * 32 + qt * 16 + lr;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            qf[qt][c] = *reinterpret_cast<const u32x4*>(Q + ((long long)head * R + grow) * 64 + c * 4 * EPC + g * EPC);
+    }
+
+    f32x4 o[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+
+    u32x4 rk[NCT], rv[NCT];
+    auto load_tile = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < NCT; ++i) {
+            const int c = tid + ATHREADS * i, row = c / SLOTS, slot = c % SLOTS;
+            rk[i] = *reinterpret_cast<const u32x4*>(Kp + ((long long)head * R + kvbase + kv0 + row) * 64 + slot * EPC);
+            rv[i] = *reinterpret_cast<const u32x4*>(Vt + ((long long)head * 64 + row) * R + kvbase + kv0 + slot * EPC);
+        }
+    };
+    auto store_tile = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < NCT; ++i) {
+            const int c = tid + ATHREADS * i, row = c / SLOTS, slot = c % SLOTS;
+            // rows/keys past the live length may hold anything (uninitialised workspace): zero them so
+            // that 0-probabilities never multiply a NaN
+            const u32x4 kz = (kv0 + row < kvlen) ? rk[i] : u32x4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(smK + lds_off<ROWB>(row, slot)) = kz;
+            *reinterpret_cast<u32x4*>(smV + lds_off<ROWB>(row, slot)) = mask_tail<Tag>(rv[i], kvlen - (kv0 + slot * EPC));
+        }
+    };
+
+    const int ntiles = (kvlen + ABK - 1) / ABK;
+    load_tile(0);
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int kv0 = tile * ABK;
+        __syncthreads();
+        store_tile(kv0);
+        __syncthreads();
+        if (tile + 1 < ntiles) load_tile(kv0 + ABK);
+
+        // ---- S^T = K Q^T  (4 key tiles x 2 query tiles)
+        f32x4 s[4][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) { s[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(smK + lds_off<ROWB>(kt * 16 + lr, c * 4 + g));
+                mma_chunk<Tag>(s[kt][0], kf, qf[0][c]);
+                mma_chunk<Tag>(s[kt][1], kf, qf[1][c]);
+            }
+        }
+        // ---- online softmax (fp32), per query column
+        const bool tail = kv0 + ABK > kvlen;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = s[kt][qt][r] * a.scale_log2e;
+                    if (tail && kv0 + kt * 16 + g * 4 + r >= kvlen) v = -INFINITY;
+                    s[kt][qt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qt], mx);   // finite: every tile holds >= 1 live key
+            const float alpha = exp2f(m_run[qt] - m_new);
+            m_run[qt] = m_new;
+            float rs = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = exp2f(s[kt][qt][r] - m_new);
+                    s[kt][qt][r] = p;
+                    rs += p;
+                }
+            l_run[qt] = l_run[qt] * alpha + rs;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt][qt] *= alpha;
+        }
+        // ---- O^T += V^T P^T
+        if constexpr (EPC == 8) {
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) {
+                const u32x4 p0 = pack8<Tag>(s[2 * tp][0], s[2 * tp + 1][0]);
+                const u32x4 p1 = pack8<Tag>(s[2 * tp][1], s[2 * tp + 1][1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int drow = dt * 16 + lr;
+                    const u32x2 v0 = *reinterpret_cast<const u32x2*>(smV + lds_off<ROWB>(drow, 4 * tp + (g >> 1)) + (g & 1) * 8);
+                    const u32x2 v1 = *reinterpret_cast<const u32x2*>(smV + lds_off<ROWB>(drow, 4 * tp + 2 + (g >> 1)) + (g & 1) * 8);
+                    const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
+                    mma_chunk<Tag>(o[dt][0], vf, p0);
+                    mma_chunk<Tag>(o[dt][1], vf, p1);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const u32x4 p0 = __builtin_bit_cast(u32x4, s[kt][0]);
+                const u32x4 p1 = __builtin_bit_cast(u32x4, s[kt][1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const u32x4 vf = *reinterpret_cast<const u32x4*>(smV + lds_off<ROWB>(dt * 16 + lr, 4 * kt + g));
+                    mma_chunk<Tag>(o[dt][0], vf, p0);
+                    mma_chunk<Tag>(o[dt][1], vf, p1);
+                }
+            }
+        }
+    }
+    // ---- normalise and store ctx[row][head*64 + d]
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = l_run[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.f / l;
+        const int qrow = t.r0 + wave * 32 + qt * 16 + lr;
+        if (qrow < qlen) {
+            float* dst = a.ctx + (t.grow0 + wave * 32 + qt * 16 + lr) * 256LL + head * 64 + g * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(dst + dt * 16) = o[dt][qt] * inv;
+        }
+    }
+}
+
+template <class Tag> static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t s) {
+    const int R = a.rs.B * (a.rs.cap0 + a.rs.cap1);
+    dim3 grid(R / ABM, 4);
+    constexpr int smem = 2 * 64 * 64 * (int)sizeof(typename Tag::elem);
+    hipLaunchKernelGGL(attn_kernel<Tag>, grid, dim3(ATHREADS), smem, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_attention(int attn_prec, const AttnArgs& a, hipStream_t s) {
+    switch (attn_prec) {
+        case PREC_F32: return launch_attn_t<TagF32>(a, s);
+        case PREC_BF16: return launch_attn_t<TagBF16>(a, s);
+        case PREC_F16: return launch_attn_t<TagF16>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace lg

@@ -1,0 +1,135 @@
+// lightglue_amd — common device helpers for gfx950 (CDNA4, wave64).
+//
+// Vocabulary used by every kernel in this directory:
+//   pair      one (image0, image1) matching problem; B pairs per forward.
+//   segment   the keypoint set of one image of one pair; seg = 2*pair + image.
+//   row       one keypoint.  All per-keypoint tensors are indexed by a GLOBAL row
+//             grow = pair*(cap0+cap1) + image*cap0 + r   (r < len[seg] <= cap{image})
+//             cap0/cap1 are multiples of 128 so that a 128-row tile never straddles segments.
+//   len[seg]  current number of live keypoints of the segment (device int; shrinks when the
+//             adaptive-width compaction prunes points).
+//   chunk     16 bytes of one operand row along the contraction axis: 8 x bf16/f16 or 4 x f32.
+//             One MFMA "step" (mma_chunk) consumes one chunk per lane of A and of B:
+//             16-bit: one v_mfma_f32_16x16x32_{bf16,f16};  f32: four v_mfma_f32_16x16x4_f32.
+//             Lane l supplies row/col (l & 15) and k-slot group g = l >> 4.  A and B use the SAME
+//             (g, element) -> k mapping, so any k permutation applied to both is harmless.
+//   C layout  acc[r] of lane l is C[row = 4*(l>>4) + r][col = l & 15]   (16x16 tile).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lg {
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// Operand precision of a contraction (host enum mirrored in include/lightglue_amd.h)
+enum : int { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2, PREC_BF16X3 = 3 };
+
+// Element tags
+struct TagF32 { typedef float elem; static constexpr int EPC = 4; };   // elements per 16-byte chunk
+struct TagBF16 { typedef bf16_t elem; static constexpr int EPC = 8; };
+struct TagF16 { typedef f16_t elem; static constexpr int EPC = 8; };
+
+// ---- one 16-byte chunk of A and of B per lane -> accumulate into a 16x16 f32 tile
+template <class Tag> __device__ __forceinline__ void mma_chunk(f32x4& acc, const u32x4& a, const u32x4& b);
+template <> __device__ __forceinline__ void mma_chunk<TagBF16>(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma_chunk<TagF16>(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma_chunk<TagF32>(f32x4& acc, const u32x4& a, const u32x4& b) {
+    const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc, 0, 0, 0);
+}
+
+// ---- fp32 -> operand conversions (round to nearest even, hardware v_cvt)
+__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v = {(bf16_t)a, (bf16_t)b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ uint32_t pack2_f16(float a, float b) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    f16x2 v = {(f16_t)a, (f16_t)b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+template <class Tag> __device__ __forceinline__ uint32_t pack2(float a, float b);
+template <> __device__ __forceinline__ uint32_t pack2<TagBF16>(float a, float b) { return pack2_bf16(a, b); }
+template <> __device__ __forceinline__ uint32_t pack2<TagF16>(float a, float b) { return pack2_f16(a, b); }
+
+__device__ __forceinline__ float bf16_round(float x) { return (float)(bf16_t)x; }
+
+// 8 floats -> one chunk of a 16-bit operand
+template <class Tag> __device__ __forceinline__ u32x4 pack8(const f32x4& lo, const f32x4& hi) {
+    u32x4 r;
+    r[0] = pack2<Tag>(lo[0], lo[1]); r[1] = pack2<Tag>(lo[2], lo[3]);
+    r[2] = pack2<Tag>(hi[0], hi[1]); r[3] = pack2<Tag>(hi[2], hi[3]);
+    return r;
+}
+// split-bf16: x = hi + lo (+ O(2^-17 x)); both halves bf16
+__device__ __forceinline__ void split8_bf16(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
+    float h[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { h[i] = bf16_round(a[i]); l[i] = a[i] - h[i]; h[4 + i] = bf16_round(b[i]); l[4 + i] = b[i] - h[4 + i]; }
+    hi[0] = pack2_bf16(h[0], h[1]); hi[1] = pack2_bf16(h[2], h[3]); hi[2] = pack2_bf16(h[4], h[5]); hi[3] = pack2_bf16(h[6], h[7]);
+    lo[0] = pack2_bf16(l[0], l[1]); lo[1] = pack2_bf16(l[2], l[3]); lo[2] = pack2_bf16(l[4], l[5]); lo[3] = pack2_bf16(l[6], l[7]);
+}
+
+// ---- LDS tile addressing.  A tile is [rows][ROWB bytes] with ROWB = 128 or 256; the 16-byte
+// slot index within a row is XOR-swizzled with a function of the row so that the 16-lane groups of
+// ds_read_b128 / the 32-lane halves of ds_read_b64 hit distinct banks (guide §2 / T2):
+//   ROWB = 128: slot ^= (row >> 1) & 7      ROWB = 256: slot ^= row & 15
+template <int ROWB> __device__ __forceinline__ int lds_off(int row, int slot16) {
+    if constexpr (ROWB == 128) return row * 128 + ((slot16 ^ ((row >> 1) & 7)) << 4);
+    else return row * 256 + ((slot16 ^ (row & 15)) << 4);
+}
+
+// ---- row space
+struct RowSpace {
+    int B;            // pairs in this forward
+    int cap0, cap1;   // per-image row capacity (multiples of 128)
+    const int* len;   // [2B] live rows per segment
+    const int* active;  // [B] 1 while the pair is still running layers (nullptr = all active)
+};
+struct TileLoc { int pair, image, seg, r0, grow0; };  // r0 = first local row of the tile
+__device__ __forceinline__ TileLoc locate_tile(const RowSpace& rs, int tile, int tile_rows) {
+    TileLoc t;
+    const int per_pair = rs.cap0 + rs.cap1;
+    t.grow0 = tile * tile_rows;
+    t.pair = t.grow0 / per_pair;
+    const int rem = t.grow0 - t.pair * per_pair;
+    t.image = rem >= rs.cap0 ? 1 : 0;
+    t.r0 = rem - t.image * rs.cap0;
+    t.seg = 2 * t.pair + t.image;
+    return t;
+}
+__device__ __forceinline__ int seg_row_base(const RowSpace& rs, int seg) {
+    return (seg >> 1) * (rs.cap0 + rs.cap1) + (seg & 1) * rs.cap0;
+}
+
+// ---- wave helpers (wave = 64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace lg

@@ -1,0 +1,526 @@
+// lightglue_amd — engine: weight re-packing, workspace, forward orchestration and the C ABI
+// (include/lightglue_amd.h).  Replaces LightGlue.__init__ weight handling (ref lightglue.py:376-437)
+// and LightGlue._forward (ref :483-629) for the hot path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/lightglue_amd.h"
+#include "lg_kernels.h"
+
+using namespace lg;
+
+namespace {
+
+thread_local std::string g_err = "";
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail(LG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
+    } while (0)
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---- host-side fp32 -> 16-bit conversions (round to nearest even)
+inline uint16_t f32_to_bf16(float f) {
+    uint32_t u; std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
+inline uint16_t f32_to_f16(float f) {
+    uint32_t x; std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0u));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);  // rounds to >= 65520 -> inf
+    if (x < 0x33000001u) return (uint16_t)sign;               // rounds to zero
+    int e = (int)(x >> 23) - 127;
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;
+    int shift;
+    uint32_t half_e;
+    if (e < -14) { shift = 13 + (-14 - e); half_e = 0; } else { shift = 13; half_e = (uint32_t)(e + 15); }
+    uint32_t r = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (r & 1u))) r++;
+    // r includes the implicit bit for normals: (half_e << 10) + (r - 0x400) == ((half_e - 1) << 10) + r
+    const uint32_t out = half_e ? (((half_e - 1u) << 10) + r) : r;
+    return (uint16_t)(sign | out);
+}
+
+struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
+
+// A device weight matrix [rows][K] in operand precision (+ lo half for split bf16)
+struct PackedW { void* hi = nullptr; void* lo = nullptr; };
+
+struct DevArena {
+    char* base = nullptr; size_t size = 0, used = 0;
+    void* take(size_t bytes) { used = (used + 255) & ~size_t(255); void* p = base + used; used += bytes; return p; }
+};
+
+}  // namespace
+
+struct lg_engine {
+    lg_config cfg{};
+    int attn_prec = 0;
+    std::map<std::string, HostTensor> staged;
+    bool weights_ready = false;
+    // ---- device weights (layer-major arrays)
+    void* w_arena = nullptr;
+    PackedW w_in, w_sqkv, w_sout, w_sf1, w_sf2, w_cqkv, w_cout, w_cf1, w_cf2, w_final;
+    float *b_in = nullptr, *b_sqkv = nullptr, *b_sout = nullptr, *b_sf1 = nullptr, *b_sf2 = nullptr, *b_cqkv = nullptr,
+          *b_cout = nullptr, *b_cf1 = nullptr, *b_cf2 = nullptr, *b_final = nullptr;
+    float *ln_s_g = nullptr, *ln_s_b = nullptr, *ln_c_g = nullptr, *ln_c_b = nullptr;  // [L][512]
+    float *w_match = nullptr, *b_match = nullptr, *w_tok = nullptr, *b_tok = nullptr;  // [L][256], [L]
+    float* Wr = nullptr;
+    // ---- workspace
+    void* ws = nullptr; size_t ws_bytes = 0;
+    int capB = 0, cap0 = 0, cap1 = 0;      // reserved
+    int cur_cap0 = 0, cur_cap1 = 0, curB = 0;
+    std::map<std::string, std::pair<void*, size_t>> bufs;
+    float *X, *CTX, *MSG, *H1, *G, *COS, *SIN, *MD, *SIM, *LS, *CONF, *MSCORE, *LSE_R, *LSE_C, *MAX0, *MAX1, *BBOX, *XIN;
+    void *Q, *K, *VT;
+    int *IND, *DST, *LEN, *LEN_OLD, *ACTIVE, *FINAL_LAYER, *ARG0, *ARG1;
+    int debug_stop = -1;
+};
+
+namespace {
+
+size_t elem_size(int prec) { return prec == PREC_F32 ? 4 : 2; }
+
+// pack a [rows][K] fp32 host matrix into operand precision at device memory
+int upload_packed(int prec, const float* src, size_t n, PackedW& dst, size_t elem_offset) {
+    const size_t es = elem_size(prec);
+    std::vector<char> hi(n * es), lo;
+    if (prec == PREC_F32) std::memcpy(hi.data(), src, n * 4);
+    else if (prec == PREC_F16) { auto* p = reinterpret_cast<uint16_t*>(hi.data()); for (size_t i = 0; i < n; ++i) p[i] = f32_to_f16(src[i]); }
+    else {
+        auto* p = reinterpret_cast<uint16_t*>(hi.data());
+        for (size_t i = 0; i < n; ++i) p[i] = f32_to_bf16(src[i]);
+        if (prec == PREC_BF16X3) {
+            lo.resize(n * es);
+            auto* q = reinterpret_cast<uint16_t*>(lo.data());
+            for (size_t i = 0; i < n; ++i) q[i] = f32_to_bf16(src[i] - bf16_to_f32(p[i]));
+        }
+    }
+    HIPCHK(hipMemcpy(static_cast<char*>(dst.hi) + elem_offset * es, hi.data(), n * es, hipMemcpyHostToDevice));
+    if (prec == PREC_BF16X3) HIPCHK(hipMemcpy(static_cast<char*>(dst.lo) + elem_offset * es, lo.data(), n * es, hipMemcpyHostToDevice));
+    return LG_OK;
+}
+
+const HostTensor* find(const lg_engine* e, const std::string& name, std::initializer_list<int64_t> shape, std::string& err) {
+    auto it = e->staged.find(name);
+    if (it == e->staged.end()) { err = "missing weight '" + name + "'"; return nullptr; }
+    if (it->second.shape != std::vector<int64_t>(shape)) { err = "bad shape for '" + name + "'"; return nullptr; }
+    return &it->second;
+}
+
+__global__ void init_state_kernel(int B, int n0, int n1, int L, int* len, int* len_old, int* active, int* final_layer,
+                                  int* prune0, int* prune1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (len && i < B) { len[2 * i] = n0; len[2 * i + 1] = n1; len_old[2 * i] = -1; len_old[2 * i + 1] = -1; active[i] = 1; final_layer[i] = L - 1; }
+    if (prune0) for (long long k = i; k < (long long)B * n0; k += (long long)gridDim.x * blockDim.x) prune0[k] = 1;
+    if (prune1) for (long long k = i; k < (long long)B * n1; k += (long long)gridDim.x * blockDim.x) prune1[k] = 1;
+}
+__global__ void write_stop_kernel(int B, const int* final_layer, int* stop) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) stop[i] = final_layer[i] + 1;
+}
+
+int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
+    const int c0 = round_up(n0 > 0 ? n0 : 1, 128), c1 = round_up(n1 > 0 ? n1 : 1, 128);
+    const bool fits = e->ws && B <= e->capB && c0 <= e->cap0 && c1 <= e->cap1;
+    if (!fits) {
+        const int nB = B > e->capB ? B : e->capB, nc0 = c0 > e->cap0 ? c0 : e->cap0, nc1 = c1 > e->cap1 ? c1 : e->cap1;
+        if (e->ws) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(e->ws)); e->ws = nullptr; }
+        e->capB = nB; e->cap0 = nc0; e->cap1 = nc1;
+        const size_t R = (size_t)nB * (nc0 + nc1), as = elem_size(e->attn_prec);
+        size_t total = 0;
+        auto add = [&](size_t b) { total = ((total + 255) & ~size_t(255)) + b; };
+        for (int i = 0; i < 3; ++i) add(R * 256 * 4);           // X CTX MSG
+        add(R * 512 * 4); add(R * 512 * 4);                     // H1 G
+        add(R * 32 * 4); add(R * 32 * 4);                       // COS SIN
+        add(R * 256 * 4);                                       // MD
+        add((size_t)nB * nc0 * nc1 * 4);                        // SIM
+        for (int i = 0; i < 3; ++i) add(R * 4);                 // LS CONF MSCORE
+        add((size_t)nB * nc0 * 4); add((size_t)nB * nc1 * 4);   // LSE_R LSE_C
+        add((size_t)nB * nc0 * 4); add((size_t)nB * nc1 * 4);   // MAX0 MAX1
+        add((size_t)nB * nc0 * 4); add((size_t)nB * nc1 * 4);   // ARG0 ARG1
+        add((size_t)nB * 8 * 4);                                // BBOX
+        add(R * (size_t)e->cfg.input_dim * 4);                  // XIN
+        for (int i = 0; i < 3; ++i) add(R * 256 * as);          // Q K VT
+        add(R * 4); add(R * 4);                                 // IND DST
+        for (int i = 0; i < 4; ++i) add((size_t)nB * 2 * 4);    // LEN LEN_OLD ACTIVE FINAL_LAYER
+        total += 4096;
+        HIPCHK(hipMalloc(&e->ws, total));
+        e->ws_bytes = total;
+    }
+    // carve for the CURRENT (B, c0, c1): buffers are laid out densely for the current shape
+    if (fits && e->curB == B && e->cur_cap0 == c0 && e->cur_cap1 == c1 && !e->bufs.empty()) return LG_OK;
+    e->curB = B; e->cur_cap0 = c0; e->cur_cap1 = c1;
+    DevArena ar{static_cast<char*>(e->ws), e->ws_bytes, 0};
+    const size_t R = (size_t)B * (c0 + c1), as = elem_size(e->attn_prec);
+    e->bufs.clear();
+    auto take = [&](const char* name, size_t bytes) { void* p = ar.take(bytes); e->bufs[name] = {p, bytes}; return p; };
+    e->X = (float*)take("X", R * 256 * 4); e->CTX = (float*)take("CTX", R * 256 * 4); e->MSG = (float*)take("MSG", R * 256 * 4);
+    e->H1 = (float*)take("H1", R * 512 * 4); e->G = (float*)take("G", R * 512 * 4);
+    e->COS = (float*)take("COS", R * 32 * 4); e->SIN = (float*)take("SIN", R * 32 * 4);
+    e->MD = (float*)take("MD", R * 256 * 4);
+    e->SIM = (float*)take("SIM", (size_t)B * c0 * c1 * 4);
+    e->LS = (float*)take("LS", R * 4); e->CONF = (float*)take("CONF", R * 4); e->MSCORE = (float*)take("MSCORE", R * 4);
+    e->LSE_R = (float*)take("LSE_R", (size_t)B * c0 * 4); e->LSE_C = (float*)take("LSE_C", (size_t)B * c1 * 4);
+    e->MAX0 = (float*)take("MAX0", (size_t)B * c0 * 4); e->MAX1 = (float*)take("MAX1", (size_t)B * c1 * 4);
+    e->ARG0 = (int*)take("ARG0", (size_t)B * c0 * 4); e->ARG1 = (int*)take("ARG1", (size_t)B * c1 * 4);
+    e->BBOX = (float*)take("BBOX", (size_t)B * 8 * 4);
+    e->XIN = (float*)take("XIN", R * (size_t)e->cfg.input_dim * 4);
+    e->Q = take("Q", R * 256 * as); e->K = take("K", R * 256 * as); e->VT = take("VT", R * 256 * as);
+    e->IND = (int*)take("IND", R * 4); e->DST = (int*)take("DST", R * 4);
+    e->LEN = (int*)take("LEN", (size_t)B * 2 * 4); e->LEN_OLD = (int*)take("LEN_OLD", (size_t)B * 2 * 4);
+    e->ACTIVE = (int*)take("ACTIVE", (size_t)B * 4); e->FINAL_LAYER = (int*)take("FINAL_LAYER", (size_t)B * 4);
+    if (ar.used > e->ws_bytes) return fail(LG_ERR_STATE, "workspace carve overflow");
+    return LG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* lg_last_error(void) { return g_err.c_str(); }
+const char* lg_version(void) { return "lightglue_amd 0.1 (gfx950)"; }
+
+int lg_engine_create(const lg_config* cfg, lg_engine** out) {
+    if (!cfg || !out) return fail(LG_ERR_INVALID, "null argument");
+    if (cfg->descriptor_dim != 256 || cfg->num_heads != 4) return fail(LG_ERR_INVALID, "only descriptor_dim=256, num_heads=4 (head_dim 64) are built");
+    if (cfg->n_layers < 1 || cfg->n_layers > 64) return fail(LG_ERR_INVALID, "bad n_layers");
+    if (cfg->input_dim <= 0 || cfg->input_dim % 64) return fail(LG_ERR_INVALID, "input_dim must be a positive multiple of 64");
+    if (cfg->precision < 0 || cfg->precision > 3) return fail(LG_ERR_INVALID, "bad precision");
+    auto* e = new lg_engine();
+    e->cfg = *cfg;
+    int ap = cfg->attn_precision;
+    if (ap < 0) ap = cfg->precision == LG_PREC_BF16X3 ? PREC_F16 : cfg->precision;
+    if (ap != PREC_F32 && ap != PREC_BF16 && ap != PREC_F16) { delete e; return fail(LG_ERR_INVALID, "bad attn_precision"); }
+    e->attn_prec = ap;
+    *out = e;
+    return LG_OK;
+}
+
+void lg_engine_destroy(lg_engine* e) {
+    if (!e) return;
+    if (e->ws) (void)hipFree(e->ws);
+    if (e->w_arena) (void)hipFree(e->w_arena);
+    delete e;
+}
+
+int lg_engine_set_weight(lg_engine* e, const char* name, const float* host_data, const int64_t* shape, int32_t ndim) {
+    if (!e || !name || !host_data || ndim < 0 || ndim > 4) return fail(LG_ERR_INVALID, "bad argument");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.assign(host_data, host_data + n);
+    e->staged[name] = std::move(t);
+    e->weights_ready = false;
+    return LG_OK;
+}
+
+int lg_engine_finalize_weights(lg_engine* e) {
+    if (!e) return fail(LG_ERR_INVALID, "null engine");
+    const int L = e->cfg.n_layers, D = 256, Din = e->cfg.input_dim, prec = e->cfg.precision;
+    const int pos_dim = 2 + 2 * (e->cfg.add_scale_ori ? 1 : 0);
+    const size_t es = elem_size(prec);
+    const bool split = prec == PREC_BF16X3;
+    // ---- size the weight arena
+    size_t total = 0;
+    auto addw = [&](size_t elems) { total = ((total + 255) & ~size_t(255)) + elems * es; if (split) total = ((total + 255) & ~size_t(255)) + elems * es; };
+    auto addf = [&](size_t n) { total = ((total + 255) & ~size_t(255)) + n * 4; };
+    addw((size_t)D * Din);
+    addw((size_t)L * 768 * D); addw((size_t)L * D * D); addw((size_t)L * 512 * 512); addw((size_t)L * D * 512);
+    addw((size_t)L * 512 * D); addw((size_t)L * D * D); addw((size_t)L * 512 * 512); addw((size_t)L * D * 512);
+    addw((size_t)L * D * D);
+    addf(D); addf((size_t)L * 768); addf((size_t)L * D); addf((size_t)L * 512); addf((size_t)L * D);
+    addf((size_t)L * 512); addf((size_t)L * D); addf((size_t)L * 512); addf((size_t)L * D); addf((size_t)L * D);
+    for (int i = 0; i < 4; ++i) addf((size_t)L * 512);
+    addf((size_t)L * D); addf(L); addf((size_t)L * D); addf(L); addf(32 * 4);
+    total += 4096;
+    if (e->w_arena) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(e->w_arena)); e->w_arena = nullptr; }
+    HIPCHK(hipMalloc(&e->w_arena, total));
+    HIPCHK(hipMemset(e->w_arena, 0, total));
+    DevArena ar{static_cast<char*>(e->w_arena), total, 0};
+    auto takew = [&](PackedW& w, size_t elems) { w.hi = ar.take(elems * es); w.lo = split ? ar.take(elems * es) : nullptr; };
+    auto takef = [&](size_t n) { return static_cast<float*>(ar.take(n * 4)); };
+    takew(e->w_in, (size_t)D * Din);
+    takew(e->w_sqkv, (size_t)L * 768 * D); takew(e->w_sout, (size_t)L * D * D); takew(e->w_sf1, (size_t)L * 512 * 512); takew(e->w_sf2, (size_t)L * D * 512);
+    takew(e->w_cqkv, (size_t)L * 512 * D); takew(e->w_cout, (size_t)L * D * D); takew(e->w_cf1, (size_t)L * 512 * 512); takew(e->w_cf2, (size_t)L * D * 512);
+    takew(e->w_final, (size_t)L * D * D);
+    e->b_in = takef(D); e->b_sqkv = takef((size_t)L * 768); e->b_sout = takef((size_t)L * D); e->b_sf1 = takef((size_t)L * 512); e->b_sf2 = takef((size_t)L * D);
+    e->b_cqkv = takef((size_t)L * 512); e->b_cout = takef((size_t)L * D); e->b_cf1 = takef((size_t)L * 512); e->b_cf2 = takef((size_t)L * D); e->b_final = takef((size_t)L * D);
+    e->ln_s_g = takef((size_t)L * 512); e->ln_s_b = takef((size_t)L * 512); e->ln_c_g = takef((size_t)L * 512); e->ln_c_b = takef((size_t)L * 512);
+    e->w_match = takef((size_t)L * D); e->b_match = takef(L); e->w_tok = takef((size_t)L * D); e->b_tok = takef(L); e->Wr = takef(32 * 4);
+
+    std::string err;
+    auto up_f32 = [&](float* dst, const float* src, size_t n) -> int { HIPCHK(hipMemcpy(dst, src, n * 4, hipMemcpyHostToDevice)); return LG_OK; };
+#define NEED(var, name, ...) const HostTensor* var = find(e, name, {__VA_ARGS__}, err); if (!var) return fail(LG_ERR_INVALID, err)
+#define TRY(x) do { int _rc = (x); if (_rc != LG_OK) return _rc; } while (0)
+    {
+        NEED(wr, "posenc.Wr.weight", 32, pos_dim);
+        TRY(up_f32(e->Wr, wr->data.data(), 32 * (size_t)pos_dim));
+    }
+    if (Din != D) {
+        NEED(w, "input_proj.weight", D, Din); NEED(b, "input_proj.bias", D);
+        TRY(upload_packed(prec, w->data.data(), (size_t)D * Din, e->w_in, 0));
+        TRY(up_f32(e->b_in, b->data.data(), D));
+    }
+    for (int i = 0; i < L; ++i) {
+        const std::string s = "transformers." + std::to_string(i) + ".self_attn.", c = "transformers." + std::to_string(i) + ".cross_attn.";
+        {   // Wqkv: reference channel = head*192 + d*3 + {q,k,v} (ref :166-167) -> packed column = which*256 + head*64 + d
+            NEED(w, s + "Wqkv.weight", 768, D); NEED(b, s + "Wqkv.bias", 768);
+            std::vector<float> pw((size_t)768 * D), pb(768);
+            for (int which = 0; which < 3; ++which) for (int h = 0; h < 4; ++h) for (int d = 0; d < 64; ++d) {
+                const int src = h * 192 + d * 3 + which, dst = which * 256 + h * 64 + d;
+                std::memcpy(&pw[(size_t)dst * D], &w->data[(size_t)src * D], D * 4);
+                pb[dst] = b->data[src];
+            }
+            TRY(upload_packed(prec, pw.data(), pw.size(), e->w_sqkv, (size_t)i * 768 * D));
+            TRY(up_f32(e->b_sqkv + (size_t)i * 768, pb.data(), 768));
+        }
+        {
+            NEED(w, s + "out_proj.weight", D, D); NEED(b, s + "out_proj.bias", D);
+            TRY(upload_packed(prec, w->data.data(), (size_t)D * D, e->w_sout, (size_t)i * D * D));
+            TRY(up_f32(e->b_sout + (size_t)i * D, b->data.data(), D));
+        }
+        for (int blk = 0; blk < 2; ++blk) {
+            const std::string& p = blk ? c : s;
+            NEED(w0, p + "ffn.0.weight", 512, 512); NEED(b0, p + "ffn.0.bias", 512);
+            NEED(g, p + "ffn.1.weight", 512); NEED(be, p + "ffn.1.bias", 512);
+            NEED(w3, p + "ffn.3.weight", D, 512); NEED(b3, p + "ffn.3.bias", D);
+            TRY(upload_packed(prec, w0->data.data(), (size_t)512 * 512, blk ? e->w_cf1 : e->w_sf1, (size_t)i * 512 * 512));
+            TRY(up_f32((blk ? e->b_cf1 : e->b_sf1) + (size_t)i * 512, b0->data.data(), 512));
+            TRY(up_f32((blk ? e->ln_c_g : e->ln_s_g) + (size_t)i * 512, g->data.data(), 512));
+            TRY(up_f32((blk ? e->ln_c_b : e->ln_s_b) + (size_t)i * 512, be->data.data(), 512));
+            TRY(upload_packed(prec, w3->data.data(), (size_t)D * 512, blk ? e->w_cf2 : e->w_sf2, (size_t)i * D * 512));
+            TRY(up_f32((blk ? e->b_cf2 : e->b_sf2) + (size_t)i * D, b3->data.data(), D));
+        }
+        {   // cross: [to_qk ; to_v] share one GEMM (both applied to both images, ref :204-205)
+            NEED(wq, c + "to_qk.weight", D, D); NEED(bq, c + "to_qk.bias", D);
+            NEED(wv, c + "to_v.weight", D, D); NEED(bv, c + "to_v.bias", D);
+            NEED(wo, c + "to_out.weight", D, D); NEED(bo, c + "to_out.bias", D);
+            std::vector<float> pw((size_t)512 * D), pb(512);
+            std::memcpy(pw.data(), wq->data.data(), (size_t)D * D * 4);
+            std::memcpy(pw.data() + (size_t)D * D, wv->data.data(), (size_t)D * D * 4);
+            std::memcpy(pb.data(), bq->data.data(), D * 4); std::memcpy(pb.data() + D, bv->data.data(), D * 4);
+            TRY(upload_packed(prec, pw.data(), pw.size(), e->w_cqkv, (size_t)i * 512 * D));
+            TRY(up_f32(e->b_cqkv + (size_t)i * 512, pb.data(), 512));
+            TRY(upload_packed(prec, wo->data.data(), (size_t)D * D, e->w_cout, (size_t)i * D * D));
+            TRY(up_f32(e->b_cout + (size_t)i * D, bo->data.data(), D));
+        }
+        {
+            const std::string a = "log_assignment." + std::to_string(i) + ".";
+            NEED(wf, a + "final_proj.weight", D, D); NEED(bf, a + "final_proj.bias", D);
+            NEED(wm, a + "matchability.weight", 1, D); NEED(bm, a + "matchability.bias", 1);
+            TRY(upload_packed(prec, wf->data.data(), (size_t)D * D, e->w_final, (size_t)i * D * D));
+            TRY(up_f32(e->b_final + (size_t)i * D, bf->data.data(), D));
+            TRY(up_f32(e->w_match + (size_t)i * D, wm->data.data(), D));
+            TRY(up_f32(e->b_match + i, bm->data.data(), 1));
+        }
+        if (i < L - 1) {
+            const std::string tkn = "token_confidence." + std::to_string(i) + ".token.0.";
+            NEED(wt, tkn + "weight", 1, D); NEED(bt, tkn + "bias", 1);
+            TRY(up_f32(e->w_tok + (size_t)i * D, wt->data.data(), D));
+            TRY(up_f32(e->b_tok + i, bt->data.data(), 1));
+        }
+    }
+#undef NEED
+    e->weights_ready = true;
+    return LG_OK;
+}
+
+int lg_engine_reserve(lg_engine* e, int32_t max_batch, int32_t max_n0, int32_t max_n1) {
+    if (!e || max_batch < 1 || max_n0 < 0 || max_n1 < 0) return fail(LG_ERR_INVALID, "bad argument");
+    return ensure_workspace(e, max_batch, max_n0, max_n1);
+}
+
+int lg_engine_debug_stop_after(lg_engine* e, int32_t step) { if (!e) return fail(LG_ERR_INVALID, "null engine"); e->debug_stop = step; return LG_OK; }
+
+int lg_engine_debug_caps(lg_engine* e, int32_t* cap0, int32_t* cap1) {
+    if (!e || !cap0 || !cap1) return fail(LG_ERR_INVALID, "null argument");
+    *cap0 = e->cur_cap0; *cap1 = e->cur_cap1;
+    return LG_OK;
+}
+
+int lg_engine_debug_read(lg_engine* e, const char* name, void* host_dst, int64_t max_bytes, int64_t* nbytes_out) {
+    if (!e || !name) return fail(LG_ERR_INVALID, "null argument");
+    auto it = e->bufs.find(name);
+    if (it == e->bufs.end()) return fail(LG_ERR_INVALID, std::string("unknown buffer '") + name + "'");
+    if (nbytes_out) *nbytes_out = (int64_t)it->second.second;
+    HIPCHK(hipDeviceSynchronize());
+    if (host_dst && max_bytes > 0) {
+        const size_t n = (size_t)max_bytes < it->second.second ? (size_t)max_bytes : it->second.second;
+        HIPCHK(hipMemcpy(host_dst, it->second.first, n, hipMemcpyDeviceToHost));
+    }
+    return LG_OK;
+}
+
+int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
+    if (!e || !io) return fail(LG_ERR_INVALID, "null argument");
+    if (!e->weights_ready) return fail(LG_ERR_STATE, "weights not finalised");
+    const int B = io->batch, n0 = io->n0, n1 = io->n1, L = e->cfg.n_layers, D = 256;
+    if (B < 1 || n0 < 0 || n1 < 0) return fail(LG_ERR_INVALID, "bad batch / keypoint counts");
+    if (!io->stop || !io->n_matches) return fail(LG_ERR_INVALID, "null output pointer");
+    if ((n0 && (!io->matches0 || !io->scores0)) || (n1 && (!io->matches1 || !io->scores1))) return fail(LG_ERR_INVALID, "null output pointer");
+    if (n0 && n1 && (!io->matches || !io->match_scores)) return fail(LG_ERR_INVALID, "null match-list pointer");
+    if (n0 && n1 && (!io->kpts0 || !io->kpts1 || !io->desc0 || !io->desc1)) return fail(LG_ERR_INVALID, "null input pointer");
+    const bool do_stop = e->cfg.depth_confidence > 0;
+    const bool do_prune = e->cfg.width_confidence > 0 && !(io->flags & LG_FLAG_NO_PRUNING);
+    if (do_prune && ((n0 && !io->prune0) || (n1 && !io->prune1))) return fail(LG_ERR_INVALID, "prune0/prune1 required when width_confidence > 0");
+    if (e->cfg.add_scale_ori && (!io->scales0 || !io->oris0 || !io->scales1 || !io->oris1)) return fail(LG_ERR_INVALID, "scales/oris required");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const int max_matches = n0 < n1 ? n0 : n1;
+
+    if (n0 == 0 || n1 == 0) {  // ref :539-540, :568-588: well-formed empty result, stop = 1
+        if (n0) { HIPCHK(hipMemsetAsync(io->matches0, 0xFF, sizeof(int) * (size_t)B * n0, s)); HIPCHK(hipMemsetAsync(io->scores0, 0, 4 * (size_t)B * n0, s)); }
+        if (n1) { HIPCHK(hipMemsetAsync(io->matches1, 0xFF, sizeof(int) * (size_t)B * n1, s)); HIPCHK(hipMemsetAsync(io->scores1, 0, 4 * (size_t)B * n1, s)); }
+        HIPCHK(hipMemsetAsync(io->n_matches, 0, sizeof(int) * (size_t)B, s));
+        hipLaunchKernelGGL(init_state_kernel, dim3(64), dim3(256), 0, s, B, n0, n1, L, nullptr, nullptr, nullptr, nullptr,
+                           (do_prune && n0) ? io->prune0 : nullptr, (do_prune && n1) ? io->prune1 : nullptr);
+        // stop = 1 for every pair
+        std::vector<int> ones(B, 1);
+        HIPCHK(hipMemcpyAsync(io->stop, ones.data(), sizeof(int) * (size_t)B, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return LG_OK;
+    }
+
+    TRY(ensure_workspace(e, B, n0, n1));
+    const int c0 = e->cur_cap0, c1 = e->cur_cap1, R = B * (c0 + c1);
+    RowSpace rs_all{B, c0, c1, e->LEN, nullptr};
+    RowSpace rs_act{B, c0, c1, e->LEN, e->ACTIVE};
+    const int prec = e->cfg.precision, ap = e->attn_prec;
+    const size_t es = elem_size(prec);
+    auto woff = [&](const PackedW& w, size_t elems) { PackedW r; r.hi = static_cast<char*>(w.hi) + elems * es; r.lo = w.lo ? static_cast<char*>(w.lo) + elems * es : nullptr; return r; };
+    int step = 0;
+#define STEP_DONE() do { if (e->debug_stop >= 0 && step >= e->debug_stop) return LG_OK; ++step; } while (0)
+
+    hipLaunchKernelGGL(init_state_kernel, dim3(64), dim3(256), 0, s, B, n0, n1, L, e->LEN, e->LEN_OLD, e->ACTIVE, e->FINAL_LAYER,
+                       do_prune ? io->prune0 : nullptr, do_prune ? io->prune1 : nullptr);
+    {
+        PrepArgs p{};
+        p.rs = rs_all; p.n0 = n0; p.n1 = n1; p.kpts0 = io->kpts0; p.kpts1 = io->kpts1; p.size0 = io->size0; p.size1 = io->size1;
+        p.scales0 = io->scales0; p.oris0 = io->oris0; p.scales1 = io->scales1; p.oris1 = io->oris1;
+        p.Wr = e->Wr; p.pos_dim = 2 + 2 * (e->cfg.add_scale_ori ? 1 : 0);
+        p.desc0 = io->desc0; p.desc1 = io->desc1; p.input_dim = e->cfg.input_dim;
+        p.X = e->X; p.Xin = e->XIN; p.cosb = e->COS; p.sinb = e->SIN; p.ind = e->IND; p.bbox = e->BBOX;
+        HIPCHK(launch_prep(p, s));
+    }
+    auto gemm = [&](int epi, const RowSpace& rs, const float* A, int lda, const float* A2, int lda2, int K1, int K,
+                    const PackedW& W, const float* bias, int Nout, float* out, int ldo, float scale) -> GemmArgs {
+        GemmArgs g{};
+        g.rs = rs; g.A = A; g.lda = lda; g.A2 = A2; g.lda2 = lda2; g.K1 = K1; g.K = K; g.W = W.hi; g.Wlo = W.lo; g.bias = bias; g.Nout = Nout;
+        g.out = out; g.ldo = ldo; g.out_scale = scale; g.R = R; (void)epi;
+        return g;
+    };
+    if (e->cfg.input_dim != D) {  // ref :521-522
+        GemmArgs g = gemm(EPI_STORE, rs_all, e->XIN, e->cfg.input_dim, nullptr, 0, e->cfg.input_dim, e->cfg.input_dim, e->w_in, e->b_in, D, e->X, D, 1.f);
+        HIPCHK(launch_gemm(prec, EPI_STORE, ap, g, s));
+    }
+    STEP_DONE();
+    const float scale_log2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+
+    for (int i = 0; i < L; ++i) {
+        for (int blk = 0; blk < 2; ++blk) {  // 0 = SelfBlock (ref :159-172), 1 = CrossBlock (ref :201-230)
+            {
+                GemmArgs g = blk == 0 ? gemm(EPI_QKV, rs_act, e->X, D, nullptr, 0, D, D, woff(e->w_sqkv, (size_t)i * 768 * D), e->b_sqkv + (size_t)i * 768, 768, nullptr, 0, 1.f)
+                                      : gemm(EPI_QKV, rs_act, e->X, D, nullptr, 0, D, D, woff(e->w_cqkv, (size_t)i * 512 * D), e->b_cqkv + (size_t)i * 512, 512, nullptr, 0, 1.f);
+                g.q = e->Q; g.k = e->K; g.vt = e->VT; g.n_qk_groups = blk == 0 ? 2 : 1;
+                g.cosb = blk == 0 ? e->COS : nullptr; g.sinb = blk == 0 ? e->SIN : nullptr;
+                HIPCHK(launch_gemm(prec, EPI_QKV, ap, g, s));
+            }
+            STEP_DONE();
+            {
+                AttnArgs at{};
+                at.rs = rs_act; at.q = e->Q; at.k = e->K; at.vt = e->VT; at.ctx = e->CTX; at.R = R; at.cross = blk; at.scale_log2e = scale_log2e;
+                HIPCHK(launch_attention(ap, at, s));
+            }
+            STEP_DONE();
+            {
+                GemmArgs g = gemm(EPI_STORE, rs_act, e->CTX, D, nullptr, 0, D, D, woff(blk ? e->w_cout : e->w_sout, (size_t)i * D * D),
+                                  (blk ? e->b_cout : e->b_sout) + (size_t)i * D, D, e->MSG, D, 1.f);
+                HIPCHK(launch_gemm(prec, EPI_STORE, ap, g, s));
+            }
+            STEP_DONE();
+            {
+                GemmArgs g = gemm(EPI_STORE, rs_act, e->X, D, e->MSG, D, D, 512, woff(blk ? e->w_cf1 : e->w_sf1, (size_t)i * 512 * 512),
+                                  (blk ? e->b_cf1 : e->b_sf1) + (size_t)i * 512, 512, e->H1, 512, 1.f);
+                HIPCHK(launch_gemm(prec, EPI_STORE, ap, g, s));
+            }
+            STEP_DONE();
+            {
+                LnGeluArgs ln{rs_act, e->H1, e->G, (blk ? e->ln_c_g : e->ln_s_g) + (size_t)i * 512, (blk ? e->ln_c_b : e->ln_s_b) + (size_t)i * 512, R};
+                HIPCHK(launch_ln_gelu(ln, s));
+            }
+            STEP_DONE();
+            {
+                GemmArgs g = gemm(EPI_RESID, rs_act, e->G, 512, nullptr, 0, 512, 512, woff(blk ? e->w_cf2 : e->w_sf2, (size_t)i * D * 512),
+                                  (blk ? e->b_cf2 : e->b_sf2) + (size_t)i * D, D, e->X, D, 1.f);
+                HIPCHK(launch_gemm(prec, EPI_RESID, ap, g, s));
+            }
+            STEP_DONE();
+        }
+        if (i == L - 1) break;  // ref :544-545
+        if (do_stop || do_prune) {
+            RowDotArgs rd{};
+            rd.rs = rs_act; rd.X = e->X;
+            if (do_stop && do_prune) {
+                rd.w0 = e->w_tok + (size_t)i * D; rd.b0 = e->b_tok + i; rd.out0 = e->CONF; rd.act0 = 1;
+                rd.w1 = e->w_match + (size_t)i * D; rd.b1 = e->b_match + i; rd.out1 = e->MSCORE; rd.act1 = 1;
+            } else if (do_stop) {
+                rd.w0 = e->w_tok + (size_t)i * D; rd.b0 = e->b_tok + i; rd.out0 = e->CONF; rd.act0 = 1;
+            } else {
+                rd.w0 = e->w_match + (size_t)i * D; rd.b0 = e->b_match + i; rd.out0 = e->MSCORE; rd.act0 = 1;
+            }
+            HIPCHK(launch_rowdot(rd, s));
+            AdaptArgs ad{};
+            ad.rs = rs_act; ad.len = e->LEN; ad.active = e->ACTIVE; ad.len_old = e->LEN_OLD; ad.final_layer = e->FINAL_LAYER;
+            ad.ind = e->IND; ad.dst = e->DST; ad.prune0 = io->prune0; ad.prune1 = io->prune1; ad.n0 = n0; ad.n1 = n1;
+            ad.conf = e->CONF; ad.mscore = e->MSCORE; ad.X = e->X; ad.cosb = e->COS; ad.sinb = e->SIN;
+            ad.layer = i;
+            // ref :631-634 threshold (float32 buffer), :656 and :640 compare in float32
+            ad.conf_thr = (float)std::fmin(std::fmax(0.8 + 0.1 * std::exp(-4.0 * i / L), 0.0), 1.0);
+            ad.depth_conf = (float)e->cfg.depth_confidence;
+            ad.width_conf = (float)(1.0 - e->cfg.width_confidence);
+            ad.pruning_min_kpts = e->cfg.pruning_min_kpts;
+            ad.do_stop = do_stop; ad.do_prune = do_prune;
+            HIPCHK(launch_adapt(ad, s));
+        }
+    }
+    // ---- log assignment with the weights of the layer each pair stopped at (ref :591)
+    {
+        RowDotArgs rd{};
+        rd.rs = rs_all; rd.X = e->X; rd.w0 = e->w_match; rd.b0 = e->b_match; rd.out0 = e->LS; rd.act0 = 2;
+        rd.layer_of_pair = e->FINAL_LAYER; rd.w_layer_stride = D; rd.ignore_active = 1;
+        HIPCHK(launch_rowdot(rd, s));
+        GemmArgs g = gemm(EPI_STORE, rs_all, e->X, D, nullptr, 0, D, D, e->w_final, e->b_final, D, e->MD, D, 0.25f);  // ref :291: / d**0.25
+        g.layer_of_pair = e->FINAL_LAYER; g.w_layer_stride = (long long)D * D; g.b_layer_stride = D;
+        HIPCHK(launch_gemm(prec, EPI_STORE, ap, g, s));
+        SimArgs sm{rs_all, e->MD, D, D, e->SIM};
+        HIPCHK(launch_sim(prec, sm, s));
+        AssignArgs as{};
+        as.rs = rs_all; as.sim = e->SIM; as.ls = e->LS; as.lse_r = e->LSE_R; as.lse_c = e->LSE_C; as.max0 = e->MAX0; as.arg0 = e->ARG0;
+        as.max1 = e->MAX1; as.arg1 = e->ARG1; as.ind = e->IND; as.n0 = n0; as.n1 = n1; as.filter_threshold = (float)e->cfg.filter_threshold;
+        as.m0 = io->matches0; as.m1 = io->matches1; as.s0 = io->scores0; as.s1 = io->scores1;
+        as.matches = io->matches; as.mscores = io->match_scores; as.n_matches = io->n_matches; as.max_matches = max_matches;
+        HIPCHK(launch_assign(as, s));
+        hipLaunchKernelGGL(write_stop_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, e->FINAL_LAYER, io->stop);
+        HIPCHK(hipGetLastError());
+    }
+#undef STEP_DONE
+#undef TRY
+    return LG_OK;
+}
+
+}  // extern "C"

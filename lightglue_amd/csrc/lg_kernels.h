@@ -1,0 +1,117 @@
+// lightglue_amd — kernel argument structs and host-side launchers (internal C++ interface;
+// the public C-ABI is include/lightglue_amd.h).
+#pragma once
+#include "lg_common.h"
+
+namespace lg {
+
+// ---------------------------------------------------------------- GEMM  (lg_gemm.hip)
+// Y[row, n] = sum_k A[row, k] * W[n, k] (+ bias[n]);  A is fp32 in HBM and converted to the operand
+// precision while it is staged into LDS; W is pre-packed in the operand precision ([Nout][K], K
+// contiguous; hi and lo halves for PREC_BF16X3).
+enum : int { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2 };
+
+struct GemmArgs {
+    RowSpace rs;
+    const float* A;  int lda;     // columns [0, K1) of the contraction
+    const float* A2; int lda2;    // columns [K1, K) (the cat[x, msg] of the FFN); nullptr when K1 == K
+    int K1, K;
+    const void* W;  const void* Wlo;  // packed weights (element type by precision)
+    const float* bias;            // [Nout] or nullptr
+    int Nout;
+    // optional per-pair layer selection (adaptive depth: the final projection uses the weights of
+    // the layer at which each pair stopped): W += layer_of_pair[pair] * w_layer_stride (elements)
+    const int* layer_of_pair; long long w_layer_stride; long long b_layer_stride;
+    // EPI_STORE / EPI_RESID
+    float* out; int ldo; float out_scale;
+    // EPI_QKV: columns are [group][head][64]; groups < n_rope_groups... see lg_gemm.hip
+    void* q; void* k; void* vt;   // q,k: [H][R][64]   vt: [H][64][R]   (element = attention type)
+    const float* cosb; const float* sinb;  // [R][32] rotary tables (nullptr = no rotary)
+    int n_qk_groups;              // 2 for self (q,k,v), 1 for cross (qk,v)
+    int R;                        // total rows (= B*(cap0+cap1))
+};
+// attn_prec selects the element type written by EPI_QKV (PREC_F32 / PREC_BF16 / PREC_F16)
+hipError_t launch_gemm(int prec, int epi, int attn_prec, const GemmArgs& a, hipStream_t s);
+
+// sim[pair][a][b] = sum_k X[row(2*pair, a), k] * X[row(2*pair+1, b), k]   (both operands fp32 rows)
+struct SimArgs {
+    RowSpace rs;
+    const float* X; int ldx; int K;
+    float* sim;   // [B][cap0][cap1]
+};
+hipError_t launch_sim(int prec, const SimArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- attention (lg_attention.hip)
+struct AttnArgs {
+    RowSpace rs;
+    const void* q; const void* k; const void* vt;  // see GemmArgs
+    float* ctx;       // [R][256] fp32, column = head*64 + d
+    int R; int cross; // cross: segment s attends to segment s^1 (q and k both read from `q`)
+    float scale_log2e;
+};
+hipError_t launch_attention(int attn_prec, const AttnArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- pointwise (lg_pointwise.hip)
+struct PrepArgs {
+    RowSpace rs;
+    int n0, n1;                    // dense input row counts per image (input tensors are [B][n][..])
+    const float* kpts0; const float* kpts1;      // [B][n][2] pixels
+    const float* size0; const float* size1;      // [B][2] (w,h) or nullptr -> bbox
+    const float* scales0; const float* oris0; const float* scales1; const float* oris1;  // [B][n] or nullptr
+    const float* Wr; int pos_dim;  // [32][pos_dim], pos_dim = 2 or 4
+    const float* desc0; const float* desc1; int input_dim;  // [B][n][input_dim]
+    float* X;                      // [R][256]  (written only when input_dim == 256; else see Xin)
+    float* Xin;                    // [R][input_dim] staging for the input projection GEMM
+    float* cosb; float* sinb;      // [R][32]
+    int* ind;                      // [R] original index of each live row
+    float* bbox;                   // [2B][4] scratch (minx,miny,maxx,maxy) when size is absent
+};
+hipError_t launch_prep(const PrepArgs& a, hipStream_t s);
+
+struct LnGeluArgs { RowSpace rs; const float* h; float* g; const float* gamma; const float* beta; int R; };
+hipError_t launch_ln_gelu(const LnGeluArgs& a, hipStream_t s);
+
+// z[row] = x[row,:] . w + b for up to two weight vectors at once (token confidence, matchability)
+struct RowDotArgs {
+    RowSpace rs; const float* X;
+    const float* w0; const float* b0; float* out0; int act0;   // act: 0 raw, 1 sigmoid, 2 logsigmoid
+    const float* w1; const float* b1; float* out1; int act1;   // w1 == nullptr -> skipped
+    const int* layer_of_pair; int w_layer_stride;              // optional per-pair layer select
+    int ignore_active;
+};
+hipError_t launch_rowdot(const RowDotArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- adaptive (lg_adaptive.hip)
+struct AdaptArgs {
+    RowSpace rs;            // rs.len / rs.active are read AND written here (non-const alias below)
+    int* len; int* active; int* len_old;
+    int* final_layer;       // [B]
+    int* ind; int* dst;     // [R]
+    int* prune0; int* prune1;   // [B][n0], [B][n1] layer counters in ORIGINAL index space
+    int n0, n1;
+    const float* conf; const float* mscore;   // [R] token confidence / matchability (sigmoid)
+    float* X; float* cosb; float* sinb;
+    int layer; float conf_thr; float depth_conf; float width_conf; int pruning_min_kpts;
+    int do_stop, do_prune;
+};
+hipError_t launch_adapt(const AdaptArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- assignment (lg_assign.hip)
+struct AssignArgs {
+    RowSpace rs;
+    const float* sim;        // [B][cap0][cap1]
+    const float* ls;         // [R] logsigmoid(matchability logit) per row
+    float* lse_r; float* lse_c;          // [B][cap0], [B][cap1]
+    float* max0; int* arg0;  // [B][cap0] row max / argmax of the score matrix
+    float* max1; int* arg1;  // [B][cap1]
+    const int* ind;          // [R]
+    int n0, n1;
+    float filter_threshold;
+    // outputs in ORIGINAL index space, pre-filled with -1 / 0 by launch_assign
+    int* m0; int* m1; float* s0; float* s1;   // [B][n0], [B][n1]
+    // compact match list (sorted by index0): [B][min(n0,n1)][2] + count
+    int* matches; float* mscores; int* n_matches; int max_matches;
+};
+hipError_t launch_assign(const AssignArgs& a, hipStream_t s);
+
+}  // namespace lg

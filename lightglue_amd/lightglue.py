@@ -1,0 +1,370 @@
+"""Host-side mirror of the reference matcher interface, backed by the HIP engine.
+
+``LightGlue(features=..., **conf).forward({'image0': ..., 'image1': ...})`` keeps the constructor
+kwargs, ``state_dict`` names/shapes, input dict and output dict of the reference class
+(``lightglue/lightglue.py:321`` ``LightGlue``; ctor :376-437, forward :456-481, output :619-629),
+but the module tree here only HOLDS parameters: all arithmetic of the forward path runs in
+hand-written gfx950 kernels reached through the C ABI (``include/lightglue_amd.h`` via
+``_cabi.py``).  There is no PyTorch / CPU fallback — ``forward`` on a non-GPU tensor, or without the
+built library, raises.
+
+Extensions over the reference (documented in DESIGN.md):
+  * batches with adaptive depth/width work for B > 1 (every pair stops / prunes independently;
+    the reference only defines this for B = 1); ``stop`` is an ``int`` for B = 1 and an
+    int64 tensor [B] for B > 1;
+  * ``precision`` conf key: "bf16x3" (default; split-bf16 linear layers + f16 attention — holds index
+    parity with the fp32 reference), "bf16", "fp16", "fp32";
+  * ``pruning_min_kpts`` conf key overrides the device-keyed class dict (ref :339-344).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+from pathlib import Path
+from types import SimpleNamespace
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _cabi
+
+
+class _Holder(nn.Module):
+    """Parameter container; never called."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("lightglue_amd parameter containers are not callable; use LightGlue.forward")
+
+
+def _ffn(d: int) -> nn.Sequential:
+    # names ffn.0 / ffn.1 / ffn.3 as in ref :152-157 (index 2 is the parameter-free GELU)
+    return nn.Sequential(nn.Linear(2 * d, 2 * d), nn.LayerNorm(2 * d, elementwise_affine=True), nn.GELU(), nn.Linear(2 * d, d))
+
+
+def _self_block(d: int) -> nn.Module:  # ref :141-157
+    m = _Holder()
+    m.Wqkv = nn.Linear(d, 3 * d)
+    m.out_proj = nn.Linear(d, d)
+    m.ffn = _ffn(d)
+    return m
+
+
+def _cross_block(d: int) -> nn.Module:  # ref :176-192
+    m = _Holder()
+    m.to_qk = nn.Linear(d, d)
+    m.to_v = nn.Linear(d, d)
+    m.to_out = nn.Linear(d, d)
+    m.ffn = _ffn(d)
+    return m
+
+
+class LightGlue(nn.Module):
+    default_conf = {
+        "name": "lightglue",
+        "input_dim": 256,
+        "descriptor_dim": 256,
+        "add_scale_ori": False,
+        "n_layers": 9,
+        "num_heads": 4,
+        "flash": True,  # kept for interface parity; attention is always the fused HIP kernel
+        "mp": False,  # kept for interface parity; see `precision`
+        "depth_confidence": 0.95,  # early stopping, disable with -1
+        "width_confidence": 0.99,  # point pruning, disable with -1
+        "filter_threshold": 0.1,
+        "weights": None,
+        # ---- lightglue_amd extensions
+        "precision": "bf16x3",
+        "pruning_min_kpts": None,  # None -> pruning_keypoint_thresholds (ref :339-344, :658-662)
+    }
+
+    # ref :339-344 (values tuned by the reference for RTX 30xx; kept for behavioural parity)
+    pruning_keypoint_thresholds = {"cpu": -1, "mps": -1, "cuda": 1024, "flash": 1536}
+
+    required_data_keys = ["image0", "image1"]
+
+    version = "v0.1_arxiv"
+    url = "https://github.com/cvg/LightGlue/releases/download/{}/{}_lightglue.pth"
+
+    features = {
+        "superpoint": {"weights": "superpoint_lightglue", "input_dim": 256},
+        "disk": {"weights": "disk_lightglue", "input_dim": 128},
+        "aliked": {"weights": "aliked_lightglue", "input_dim": 128},
+        "sift": {"weights": "sift_lightglue", "input_dim": 128, "add_scale_ori": True},
+        "doghardnet": {"weights": "doghardnet_lightglue", "input_dim": 128, "add_scale_ori": True},
+    }
+
+    def __init__(self, features="superpoint", **conf) -> None:
+        super().__init__()
+        self.conf = conf = SimpleNamespace(**{**self.default_conf, **conf})
+        if features is not None:
+            if features not in self.features:
+                raise ValueError(f"Unsupported features: {features} not in {{{','.join(self.features)}}}")
+            for k, v in self.features[features].items():
+                setattr(conf, k, v)
+        if conf.precision not in _cabi.LG_PREC:
+            raise ValueError(f"precision must be one of {sorted(_cabi.LG_PREC)}")
+        if conf.descriptor_dim != 256 or conf.num_heads != 4:
+            raise ValueError("lightglue_amd builds descriptor_dim=256, num_heads=4 (head_dim 64) only")
+
+        d, L = conf.descriptor_dim, conf.n_layers
+        self.input_proj = nn.Linear(conf.input_dim, d, bias=True) if conf.input_dim != d else nn.Identity()
+        self.posenc = _Holder()
+        self.posenc.Wr = nn.Linear(2 + 2 * int(conf.add_scale_ori), d // conf.num_heads // 2, bias=False)
+        nn.init.normal_(self.posenc.Wr.weight.data, mean=0, std=1.0)  # ref :74 (gamma = 1)
+        layers = []
+        for _ in range(L):
+            layer = _Holder()
+            layer.self_attn = _self_block(d)
+            layer.cross_attn = _cross_block(d)
+            layers.append(layer)
+        self.transformers = nn.ModuleList(layers)
+        assign = []
+        for _ in range(L):
+            a = _Holder()
+            a.matchability = nn.Linear(d, 1, bias=True)
+            a.final_proj = nn.Linear(d, d, bias=True)
+            assign.append(a)
+        self.log_assignment = nn.ModuleList(assign)
+        toks = []
+        for _ in range(L - 1):
+            t = _Holder()
+            t.token = nn.Sequential(nn.Linear(d, 1), nn.Sigmoid())
+            toks.append(t)
+        self.token_confidence = nn.ModuleList(toks)
+        self.register_buffer("confidence_thresholds", torch.Tensor([self.confidence_threshold(i) for i in range(L)]))
+
+        state_dict = None
+        if features is not None:
+            state_dict = self._find_pretrained(features, conf.weights)
+        elif conf.weights is not None:
+            path = Path(__file__).parent / "weights" / f"{conf.weights}.pth"
+            state_dict = torch.load(str(path), map_location="cpu")
+        if state_dict:
+            # legacy key names (ref :427-434)
+            for i in range(L):
+                state_dict = {k.replace(f"self_attn.{i}", f"transformers.{i}.self_attn"): v for k, v in state_dict.items()}
+                state_dict = {k.replace(f"cross_attn.{i}", f"transformers.{i}.cross_attn"): v for k, v in state_dict.items()}
+            self.load_state_dict(state_dict, strict=False)
+
+        self.static_lengths = None
+        self._engine = None  # (handle, device_index, config signature)
+        self._weights_sig = None
+        self.requires_grad_(False)
+
+    # ------------------------------------------------------------------ weights
+    def _find_pretrained(self, features: str, weights: str):
+        """The reference downloads `{features}_lightglue.pth` (ref :416-421).  Look for the same file
+        where torch.hub would have cached it or in ./weights; download only if the network allows."""
+        fname = f"{weights}_{self.version.replace('.', '-')}.pth"
+        candidates = [Path(torch.hub.get_dir()) / "checkpoints" / fname, Path(__file__).parent / "weights" / fname,
+                      Path(__file__).parent / "weights" / f"{weights}.pth"]
+        for c in candidates:
+            if c.exists():
+                return torch.load(str(c), map_location="cpu")
+        try:
+            return torch.hub.load_state_dict_from_url(self.url.format(self.version, features), file_name=fname, map_location="cpu")
+        except Exception as exc:  # offline
+            raise RuntimeError(
+                f"pretrained weights '{fname}' not found in {[str(c.parent) for c in candidates]} and download failed "
+                f"({exc}); place the file there or construct LightGlue(features=None, input_dim=...) and load_state_dict()."
+            ) from exc
+
+    def confidence_threshold(self, layer_index: int) -> float:
+        """ref :631-634"""
+        threshold = 0.8 + 0.1 * np.exp(-4.0 * layer_index / self.conf.n_layers)
+        return np.clip(threshold, 0, 1)
+
+    def pruning_min_kpts(self, device: torch.device) -> int:
+        """ref :658-662.  ROCm devices report type 'cuda'; the fused attention kernel plays the role of
+        the reference's flash path."""
+        if self.conf.pruning_min_kpts is not None:
+            return int(self.conf.pruning_min_kpts)
+        if self.conf.flash and device.type == "cuda":
+            return self.pruning_keypoint_thresholds["flash"]
+        return self.pruning_keypoint_thresholds[device.type]
+
+    def compile(self, mode="reduce-overhead", static_lengths=[256, 512, 768, 1024, 1280, 1536]):
+        """Interface parity with ref :439-454.  Nothing is traced here: the HIP kernels take ragged
+        lengths natively, so no padding happens.  As in the reference (ref :529), point pruning is
+        disabled for inputs that fall inside the static-length range."""
+        if self.conf.width_confidence != -1:
+            warnings.warn("Point pruning is partially disabled for compiled forward.", stacklevel=2)
+        self.static_lengths = list(static_lengths)
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _config_sig(self, device: torch.device):
+        c = self.conf
+        return (device.index if device.index is not None else torch.cuda.current_device(), c.input_dim, c.n_layers, bool(c.add_scale_ori),
+                float(c.depth_confidence), float(c.width_confidence), float(c.filter_threshold), self.pruning_min_kpts(device), c.precision)
+
+    def _get_engine(self, device: torch.device):
+        lib = _cabi.load()
+        sig = self._config_sig(device)
+        if self._engine is not None and self._engine[1] == sig:
+            return self._engine[0]
+        self._drop_engine()
+        c = self.conf
+        cfg = _cabi.LgConfig(c.input_dim, c.descriptor_dim, c.n_layers, c.num_heads, int(bool(c.add_scale_ori)),
+                             float(c.depth_confidence), float(c.width_confidence), float(c.filter_threshold),
+                             int(sig[7]), _cabi.LG_PREC[c.precision], -1)
+        handle = C.c_void_p()
+        with torch.cuda.device(device):
+            _cabi.check(lib.lg_engine_create(C.byref(cfg), C.byref(handle)))
+        self._engine = (handle, sig)
+        self._weights_sig = None
+        return handle
+
+    def _drop_engine(self):
+        if getattr(self, "_engine", None) is not None:
+            try:
+                _cabi.load().lg_engine_destroy(self._engine[0])
+            except Exception:  # pragma: no cover
+                pass
+            self._engine = None
+
+    def __del__(self):  # pragma: no cover
+        self._drop_engine()
+
+    def _sync_weights(self, handle, device):
+        """Re-pack and upload whenever any parameter changed (load_state_dict, .to(), in-place edit)."""
+        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if sig == self._weights_sig:
+            return
+        lib = _cabi.load()
+        keep = []
+        for name, p in self.state_dict().items():
+            if name == "confidence_thresholds":
+                continue
+            arr = p.detach().to("cpu", torch.float32).contiguous().numpy()
+            keep.append(arr)
+            shape = (C.c_int64 * arr.ndim)(*arr.shape)
+            _cabi.check(lib.lg_engine_set_weight(handle, name.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim))
+        with torch.cuda.device(device):
+            _cabi.check(lib.lg_engine_finalize_weights(handle))
+        self._weights_sig = sig
+
+    def reserve(self, batch: int, n0: int, n1: int, device=None):
+        """Pre-size the engine workspace (avoids a synchronising re-allocation inside forward)."""
+        device = torch.device(device if device is not None else "cuda")
+        h = self._get_engine(device)
+        self._sync_weights(h, device)
+        with torch.cuda.device(device):
+            _cabi.check(_cabi.load().lg_engine_reserve(h, batch, n0, n1))
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, data: dict) -> dict:
+        """Match keypoints and descriptors between two images (same dict contract as ref :456-481).
+
+        Input (dict):  image0/image1: {keypoints [B,N,2], descriptors [B,N,D], image_size [B,2] (optional),
+                                       scales/oris [B,N] iff add_scale_ori}
+        Output (dict): matches0 [B,M] int64, matching_scores0 [B,M], matches1 [B,N], matching_scores1 [B,N],
+                       matches List[[S_i,2]], scores List[[S_i]], stop, prune0 [B,M], prune1 [B,N]
+        """
+        for key in self.required_data_keys:
+            assert key in data, f"Missing key {key} in data"
+        d0, d1 = data["image0"], data["image1"]
+        kpts0, kpts1 = d0["keypoints"], d1["keypoints"]
+        device = kpts0.device
+        if device.type != "cuda":
+            raise RuntimeError("lightglue_amd runs on MI355X (ROCm device type 'cuda') only; there is no CPU fallback. "
+                               f"Got keypoints on {device}.")
+        b, m, _ = kpts0.shape
+        b, n, _ = kpts1.shape
+        conf = self.conf
+        f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+        k0, k1 = f32(kpts0), f32(kpts1)
+        desc0, desc1 = f32(d0["descriptors"]), f32(d1["descriptors"])
+        assert desc0.shape[-1] == conf.input_dim
+        assert desc1.shape[-1] == conf.input_dim
+        size0, size1 = d0.get("image_size"), d1.get("image_size")
+
+        def as_size(s):
+            if s is None:
+                return None
+            if not isinstance(s, torch.Tensor):
+                s = torch.tensor(s, dtype=torch.float32)
+            s = f32(s)
+            return s.expand(b, 2).contiguous() if s.dim() == 1 else s
+
+        size0, size1 = as_size(size0), as_size(size1)
+        extra = [None] * 4
+        if conf.add_scale_ori:
+            extra = [f32(d0["scales"]), f32(d0["oris"]), f32(d1["scales"]), f32(d1["oris"])]
+
+        do_early_stop = conf.depth_confidence > 0
+        do_compile = bool(self.static_lengths) and max(m, n) <= max(self.static_lengths)
+        do_point_pruning = conf.width_confidence > 0 and not do_compile
+
+        i32 = dict(device=device, dtype=torch.int32)
+        m0 = torch.empty((b, m), **i32)
+        m1 = torch.empty((b, n), **i32)
+        ms0 = torch.empty((b, m), device=device, dtype=torch.float32)
+        ms1 = torch.empty((b, n), device=device, dtype=torch.float32)
+        stop = torch.empty((b,), **i32)
+        kmax = min(m, n)
+        mlist = torch.empty((b, kmax, 2), **i32)
+        mscore_list = torch.empty((b, kmax), device=device, dtype=torch.float32)
+        n_matches = torch.empty((b,), **i32)
+        prune0 = torch.empty((b, m), **i32) if do_point_pruning else None
+        prune1 = torch.empty((b, n), **i32) if do_point_pruning else None
+
+        handle = self._get_engine(device)
+        self._sync_weights(handle, device)
+        ptr = lambda t: None if t is None or t.numel() == 0 else t.data_ptr()
+        io = _cabi.LgForwardIO(
+            b, m, n, 0 if do_point_pruning or conf.width_confidence <= 0 else _cabi.LG_FLAG_NO_PRUNING,
+            ptr(k0), ptr(k1), ptr(desc0), ptr(desc1), ptr(size0), ptr(size1),
+            ptr(extra[0]), ptr(extra[1]), ptr(extra[2]), ptr(extra[3]),
+            ptr(m0), ptr(m1), ptr(ms0), ptr(ms1), stop.data_ptr(), ptr(prune0), ptr(prune1),
+            ptr(mlist), ptr(mscore_list), n_matches.data_ptr())
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _cabi.check(_cabi.load().lg_engine_forward(handle, C.byref(io), C.c_void_p(stream)))
+
+        # ---- output assembly (ref :593-629)
+        counts = n_matches.tolist()  # the one host synchronisation of the forward (ragged lists need sizes)
+        matches = [mlist[k, : counts[k]].long() for k in range(b)]
+        mscores = [mscore_list[k, : counts[k]] for k in range(b)]
+        if do_point_pruning:
+            prune0, prune1 = prune0.long(), prune1.long()
+        else:  # ref :616-617
+            prune0 = torch.ones_like(ms0) * conf.n_layers
+            prune1 = torch.ones_like(ms1) * conf.n_layers
+        if not do_early_stop and m > 0 and n > 0:
+            stop_out = conf.n_layers if b == 1 else torch.full((b,), conf.n_layers, device=device, dtype=torch.long)
+        else:
+            stop_out = int(stop[0].item()) if b == 1 else stop.long()
+        return {
+            "matches0": m0.long(),
+            "matches1": m1.long(),
+            "matching_scores0": ms0,
+            "matching_scores1": ms1,
+            "stop": stop_out,
+            "matches": matches,
+            "scores": mscores,
+            "prune0": prune0,
+            "prune1": prune1,
+        }
+
+    # ------------------------------------------------------------------ test / profiling taps
+    def debug_stop_after(self, step: int, device="cuda"):
+        h = self._get_engine(torch.device(device))
+        _cabi.check(_cabi.load().lg_engine_debug_stop_after(h, int(step)))
+
+    def debug_read(self, name: str, dtype=np.float32, device="cuda") -> np.ndarray:
+        h = self._get_engine(torch.device(device))
+        lib = _cabi.load()
+        nbytes = C.c_int64()
+        _cabi.check(lib.lg_engine_debug_read(h, name.encode(), None, 0, C.byref(nbytes)))
+        out = np.empty(nbytes.value // np.dtype(dtype).itemsize, dtype=dtype)
+        _cabi.check(lib.lg_engine_debug_read(h, name.encode(), out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(nbytes)))
+        return out
+
+    def debug_caps(self, device="cuda"):
+        h = self._get_engine(torch.device(device))
+        c0, c1 = C.c_int32(), C.c_int32()
+        _cabi.check(_cabi.load().lg_engine_debug_caps(h, C.byref(c0), C.byref(c1)))
+        return c0.value, c1.value

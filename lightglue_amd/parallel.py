@@ -1,0 +1,109 @@
+"""Pair-sharded data parallelism over the GPUs of one node.
+
+Image pairs are fully independent (no cross-pair op anywhere in the reference's ``_forward``), so the
+batch shards by contiguous blocks of pairs with NO data-path collective; one process per GPU
+(``torchrun``), weights replicated.  The only exchange is the result gather: ONE fixed-shape
+``all_gather_into_tensor`` of a packed int32 buffer per batch (match indices; scores are carried as
+their fp32 bit patterns in the same buffer) — RCCL over xGMI on the GPU (backend "nccl"), gloo in
+the CPU tests.  Payload is a few MB at most, i.e. latency-bound on the xGMI ring; it is issued on the
+caller's stream right after the local forward.
+
+The ragged ``matches`` lists are rebuilt from ``matches0`` after the gather (no variable-size
+collective).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(batch: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block of pairs owned by ``rank``: sizes differ by at most one."""
+    base, rem = divmod(batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _slice_data(data: dict, lo: int, hi: int) -> dict:
+    return {k: ({kk: vv[lo:hi] for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in data.items()}
+
+
+class PairShardedMatcher:
+    """Wraps a per-process matcher (``LightGlue`` on this rank's GPU, or any callable with the same dict
+    contract) and returns full-batch results on every rank.
+
+    ``forward(data)``: ``data`` holds the FULL batch on every rank (the usual case when a loader feeds
+    identical manifests) — each rank matches its shard and the results are all-gathered;
+    ``forward_local(local_data, global_batch)`` takes the already-sharded local pairs.
+    """
+
+    def __init__(self, matcher: Callable[[dict], dict], group=None):
+        self.matcher = matcher
+        self.group = group
+
+    @property
+    def world(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    @property
+    def rank(self) -> int:
+        return dist.get_rank(self.group) if dist.is_initialized() else 0
+
+    def forward(self, data: dict) -> Dict[str, torch.Tensor]:
+        batch = data["image0"]["keypoints"].shape[0]
+        lo, hi = shard_range(batch, self.rank, self.world)
+        return self.forward_local(_slice_data(data, lo, hi), batch)
+
+    __call__ = forward
+
+    def forward_local(self, local: dict, global_batch: int) -> Dict[str, torch.Tensor]:
+        m = local["image0"]["keypoints"].shape[1]
+        n = local["image1"]["keypoints"].shape[1]
+        world, rank = self.world, self.rank
+        lo, hi = shard_range(global_batch, rank, world)
+        nloc = hi - lo
+        assert local["image0"]["keypoints"].shape[0] == nloc, "local shard size does not match shard_range"
+        dev = local["image0"]["keypoints"].device
+        out = self.matcher(local) if nloc > 0 else None
+        # ---- pack [pairs_max][2m + 2n + 1] int32: matches0 | bits(scores0) | matches1 | bits(scores1) | stop
+        per_rank = (global_batch + world - 1) // world
+        width = 2 * m + 2 * n + 1
+        buf = torch.zeros((per_rank, width), dtype=torch.int32, device=dev)
+        if nloc > 0:
+            stop = out["stop"]
+            stop_t = torch.full((nloc,), int(stop), dtype=torch.int32, device=dev) if not torch.is_tensor(stop) else stop.to(dev, torch.int32).reshape(nloc)
+            buf[:nloc, 0:m] = out["matches0"].to(torch.int32)
+            buf[:nloc, m:2 * m] = out["matching_scores0"].to(torch.float32).contiguous().view(torch.int32)
+            buf[:nloc, 2 * m:2 * m + n] = out["matches1"].to(torch.int32)
+            buf[:nloc, 2 * m + n:2 * m + 2 * n] = out["matching_scores1"].to(torch.float32).contiguous().view(torch.int32)
+            buf[:nloc, -1] = stop_t
+        if world > 1:
+            gathered = torch.empty((world * per_rank, width), dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(gathered, buf, group=self.group)
+            rows = []
+            for r in range(world):
+                rlo, rhi = shard_range(global_batch, r, world)
+                rows.append(gathered[r * per_rank: r * per_rank + (rhi - rlo)])
+            full = torch.cat(rows, 0)
+        else:
+            full = buf[:nloc]
+        m0 = full[:, 0:m].long()
+        ms0 = full[:, m:2 * m].contiguous().view(torch.float32)
+        m1 = full[:, 2 * m:2 * m + n].long()
+        ms1 = full[:, 2 * m + n:2 * m + 2 * n].contiguous().view(torch.float32)
+        stop = full[:, -1].long()
+        return {"matches0": m0, "matches1": m1, "matching_scores0": ms0, "matching_scores1": ms1, "stop": stop}
+
+    @staticmethod
+    def ragged(result: Dict[str, torch.Tensor]):
+        """Rebuild the reference's ragged `matches` / `scores` lists (ref lightglue.py:593-602) from the
+        gathered fixed-shape tensors."""
+        matches, scores = [], []
+        for k in range(result["matches0"].shape[0]):
+            valid = result["matches0"][k] > -1
+            i0 = torch.where(valid)[0]
+            matches.append(torch.stack([i0, result["matches0"][k][valid]], -1))
+            scores.append(result["matching_scores0"][k][valid])
+        return matches, scores

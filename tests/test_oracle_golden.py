@@ -1,0 +1,61 @@
+"""The oracle (oracle/lightglue_oracle.py) against the golden vectors produced by the real reference
+(tools/make_golden.py), and live against the reference module when /root/reference is present."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden, oracle_conf_for
+from oracle import lightglue_oracle as O, synth
+import make_golden
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_matches_reference_golden(name):
+    meta, gold = load_golden(name)
+    case = meta["case"]
+    sd, data = make_golden.case_inputs(case)
+    assert synth.state_dict_digest(sd) == meta["weights_sha256"], "seeded weight generator drifted"
+    out = O.forward(sd, oracle_conf_for(case), data)
+    np.testing.assert_array_equal(out["matches0"], gold["matches0"])
+    np.testing.assert_array_equal(out["matches1"], gold["matches1"])
+    np.testing.assert_allclose(out["matching_scores0"], gold["matching_scores0"], atol=2e-4, rtol=0)
+    np.testing.assert_allclose(out["matching_scores1"], gold["matching_scores1"], atol=2e-4, rtol=0)
+    assert out["stop"] == gold["stop"].tolist()
+    np.testing.assert_array_equal(np.asarray(out["prune0"], np.float32), gold["prune0"])
+    np.testing.assert_array_equal(np.asarray(out["prune1"], np.float32), gold["prune1"])
+    assert [len(m) for m in out["matches"]] == gold["n_matches"].tolist()
+    for b, ml in enumerate(out["matches"]):  # sorted by index0 (torch.where order, ref :596)
+        assert np.all(np.diff(ml[:, 0]) > 0)
+        np.testing.assert_array_equal(ml[:, 1], out["matches0"][b][ml[:, 0]])
+
+
+@pytest.mark.skipif(not make_golden.REF.exists(), reason="reference tree not mounted")
+def test_oracle_live_against_reference():
+    lg = make_golden.load_reference()
+    case = dict(recipe="A", wseed=5, dseed=123, B=1, n=160, m=140, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1))
+    sd, ref = make_golden.run_reference(lg, case)
+    _, data = make_golden.case_inputs(case)
+    out = O.forward(sd, oracle_conf_for(case), data)
+    np.testing.assert_array_equal(out["matches0"], ref["matches0"])
+    np.testing.assert_allclose(out["matching_scores0"], ref["matching_scores0"], atol=2e-4)
+
+
+def test_float64_truth_agrees_with_fp32_reference():
+    meta, gold = load_golden("nonadaptive_bbox_300x200")
+    sd, data = make_golden.case_inputs(meta["case"])
+    out = O.forward(sd, oracle_conf_for(meta["case"]), data, dtype=np.float64)
+    assert (out["matches0"] != gold["matches0"]).sum() == 0
+    assert np.abs(out["matching_scores0"] - gold["matching_scores0"]).max() < 2e-4
+
+
+def test_operand_rounding_emulation_orders():
+    """split-bf16 operands must be far closer to fp32 than plain bf16 (this is what justifies the
+    default precision of the HIP path)."""
+    meta, gold = load_golden("nonadaptive_bbox_300x200")
+    sd, data = make_golden.case_inputs(meta["case"])
+    conf = oracle_conf_for(meta["case"])
+    e = {}
+    for q in ("bf16", {"lin": "bf16x2", "attn": "fp16", "final": "bf16x2"}):
+        out = O.forward(sd, conf, data, quant=q)
+        e[str(q)] = np.abs(out["matching_scores0"] - gold["matching_scores0"]).max()
+    vals = list(e.values())
+    assert vals[1] < 1e-3 < vals[0], e

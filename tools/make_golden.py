@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference matcher in this container.
+
+The reference module is loaded standalone from /root/reference/lightglue/lightglue.py (its package
+__init__ needs torchvision/kornia/cv2 which are absent) on CPU in fp32.  Weights and
+inputs are regenerated from seeds by oracle/synth.py (numpy only), so a fixture stores just the case
+description, a digest of the weights, and the reference outputs.
+
+    python tools/make_golden.py            # rewrites every fixture
+The fixtures are committed; the GPU box never needs /root/reference.
+"""
+from __future__ import annotations
+
+import importlib.util
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from oracle import synth  # noqa: E402
+
+REF = Path("/root/reference/lightglue/lightglue.py")
+
+# name -> case description.  `conf` are LightGlue kwargs; `prune_th` sets the reference's class dict
+# LightGlue.pruning_keypoint_thresholds (all device keys) like benchmark.py:178-181 does.
+CASES = {
+    "nonadaptive_512": dict(recipe="A", wseed=0, dseed=1, B=1, n=512, m=512, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1)),
+    "nonadaptive_b3_256x192": dict(recipe="A", wseed=0, dseed=11, B=3, n=256, m=192, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1)),
+    "nonadaptive_bbox_300x200": dict(recipe="A", wseed=0, dseed=21, B=1, n=300, m=200, dim=256, no_size=True, conf=dict(depth_confidence=-1, width_confidence=-1)),
+    "disk128_256x320": dict(recipe="A", wseed=3, dseed=31, B=1, n=256, m=320, dim=128, conf=dict(depth_confidence=-1, width_confidence=-1, input_dim=128)),
+    "sift_scale_ori_200x180": dict(recipe="A", wseed=4, dseed=41, B=1, n=200, m=180, dim=128, conf=dict(depth_confidence=-1, width_confidence=-1, input_dim=128, add_scale_ori=True)),
+    "mutualnn_filter0_512": dict(recipe=None, wseed=0, dseed=51, B=1, n=512, m=512, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1, filter_threshold=0.0)),
+    "adaptive_1024": dict(recipe="B", wseed=0, dseed=61, B=1, n=1024, m=1024, dim=256, prune_th=-1, conf=dict()),
+    "adaptive_asym_800x300": dict(recipe="B", wseed=0, dseed=71, B=1, n=800, m=300, dim=256, prune_th=-1, conf=dict()),
+    "adaptive_prune_th512_700x400": dict(recipe="B", wseed=0, dseed=81, B=1, n=700, m=400, dim=256, prune_th=512, conf=dict()),
+    "stop_only_600": dict(recipe="B", wseed=0, dseed=91, B=1, n=600, m=600, dim=256, prune_th=-1, conf=dict(width_confidence=-1)),
+    "prune_only_600": dict(recipe="B", wseed=0, dseed=101, B=1, n=600, m=600, dim=256, prune_th=-1, conf=dict(depth_confidence=-1)),
+    "empty_0x50": dict(recipe="A", wseed=0, dseed=111, B=1, n=0, m=50, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1)),
+}
+
+
+def load_reference():
+    spec = importlib.util.spec_from_file_location("lg_ref", str(REF))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def case_inputs(case: dict):
+    """Weights (numpy state dict) and the input dict of a case; shared with the tests."""
+    conf = case["conf"]
+    sd = synth.make_state_dict(case["wseed"], input_dim=conf.get("input_dim", 256), add_scale_ori=conf.get("add_scale_ori", False), recipe=case["recipe"])
+    if case["n"] == 0 or case["m"] == 0:
+        rng = np.random.Generator(np.random.PCG64(case["dseed"]))
+        def img(k):
+            d = rng.standard_normal((case["B"], k, case["dim"])).astype(np.float32)
+            return {"keypoints": (rng.random((case["B"], k, 2)) * 500).astype(np.float32), "descriptors": d,
+                    "image_size": np.tile(np.array([[1024.0, 768.0]], np.float32), (case["B"], 1))}
+        data = {"image0": img(case["n"]), "image1": img(case["m"])}
+    else:
+        data = synth.make_batch(case["dseed"], case["B"], case["n"], case["m"], case["dim"], add_scale_ori=conf.get("add_scale_ori", False))
+    if case.get("no_size"):
+        for k in ("image0", "image1"):
+            data[k].pop("image_size")
+    return sd, data
+
+
+def run_reference(lg, case: dict):
+    sd, data = case_inputs(case)
+    torch.set_grad_enabled(False)
+    torch.manual_seed(0)
+    saved = dict(lg.LightGlue.pruning_keypoint_thresholds)
+    if "prune_th" in case:
+        for k in lg.LightGlue.pruning_keypoint_thresholds:
+            lg.LightGlue.pruning_keypoint_thresholds[k] = case["prune_th"]
+    try:
+        model = lg.LightGlue(features=None, **case["conf"]).eval()
+        res = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        assert not res.unexpected_keys and set(res.missing_keys) <= {"confidence_thresholds"}, res
+        outs = []
+        for b in range(case["B"]):  # B = 1 calls: the reference's adaptive path is B=1-only, and batched == per-pair otherwise
+            td = {k: {kk: torch.from_numpy(vv[b:b + 1]) for kk, vv in v.items()} for k, v in data.items()}
+            outs.append(model(td))
+    finally:
+        lg.LightGlue.pruning_keypoint_thresholds.update(saved)
+    out = {
+        "matches0": np.stack([o["matches0"][0].numpy() for o in outs]).astype(np.int64),
+        "matches1": np.stack([o["matches1"][0].numpy() for o in outs]).astype(np.int64),
+        "matching_scores0": np.stack([o["matching_scores0"][0].numpy() for o in outs]).astype(np.float32),
+        "matching_scores1": np.stack([o["matching_scores1"][0].numpy() for o in outs]).astype(np.float32),
+        "stop": np.array([int(o["stop"]) for o in outs], np.int64),
+        "prune0": np.stack([o["prune0"][0].numpy() for o in outs]).astype(np.float32),
+        "prune1": np.stack([o["prune1"][0].numpy() for o in outs]).astype(np.float32),
+        "n_matches": np.array([o["matches"][0].shape[0] for o in outs], np.int64),
+    }
+    return sd, out
+
+
+def main():
+    lg = load_reference()
+    out_dir = ROOT / "tests" / "golden"
+    out_dir.mkdir(parents=True, exist_ok=True)
+    for name, case in CASES.items():
+        sd, out = run_reference(lg, case)
+        meta = dict(case=case, weights_sha256=synth.state_dict_digest(sd), torch=torch.__version__, numpy=np.__version__,
+                    reference="cvg/LightGlue lightglue/lightglue.py (CPU fp32, loaded standalone)")
+        np.savez_compressed(out_dir / f"{name}.npz", meta=json.dumps(meta), **out)
+        hist0 = np.bincount(out["prune0"].astype(np.int64).ravel(), minlength=10).tolist() if out["prune0"].size else []
+        print(f"{name:32s} matches {out['n_matches'].tolist()} stop {out['stop'].tolist()} prune0 hist {hist0}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the MI355X-native LightGlue matcher forward path.
+
+Metric (BASELINE.json): image-pairs/s at N=M=1024 SuperPoint-dim descriptors, 9 layers, pruning
+and early-stop OFF, batch 32 pairs per GPU, inputs resident in HBM, synthetic data / seeded weights.
+One "step" = one LightGlue.forward over one batch of 32 pairs (the whole reference forward: layers,
+log-assignment, match filtering and the ragged match lists).
+
+    python bench.py [--gpus N --steps K --warmup W] [--precision bf16x3|bf16|fp16|fp32]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU, every rank matches its own 32 pairs (weak scaling, no data-path
+collective) and the match indices are all-gathered over RCCL each step (lightglue_amd.parallel).
+
+Prints ONE JSON line on rank 0 with the driver's contract plus
+  roofline     — dominant kernel class, measured with HIP events on the launch stream over the timed
+                 region (engine-side events, include/lightglue_amd.h lg_engine_profile_*)
+  cpu_baseline — the numpy port of the reference (oracle/) timed on this host's cores on a bounded
+                 sample of the same workload (N=1, rank 0 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from lightglue_amd import LightGlue, PairShardedMatcher  # noqa: E402
+from lightglue_amd import synthetic  # noqa: E402
+
+N_KPTS = 1024
+PAIRS_PER_GPU = 32
+D = 256
+L = 9
+
+# ---- algorithmic FLOPs (2 per MAC), SURVEY.md §8d.  Per launch of each kernel class over `pairs` pairs.
+def flops_per_launch(pairs: int, n: int, m: int):
+    pts = pairs * (n + m)
+    return {
+        "gemm_qkv_self": 2.0 * pts * 256 * 768,
+        "gemm_qkv_cross": 2.0 * pts * 256 * 512,
+        "gemm_out_proj": 2.0 * pts * 256 * 256,
+        "gemm_ffn0": 2.0 * pts * 512 * 512,
+        "gemm_ffn3_resid": 2.0 * pts * 512 * 256,
+        "gemm_final_proj": 2.0 * pts * 256 * 256,
+        "attn_self": pairs * 4.0 * 256 * (n * n + m * m),          # QK^T + PV per image
+        "attn_cross": pairs * 8.0 * 256 * n * m,                   # two directions, S computed twice
+        "sim": pairs * 2.0 * 256 * n * m,
+    }
+
+
+def flops_per_pair(n: int, m: int) -> float:
+    """80.53 GFLOP at n = m = 1024 (shared-S accounting for cross attention)."""
+    per_pt_layer = 1_310_720 + 1_179_648
+    return L * (per_pt_layer * (n + m) + 4 * D * (n * n + m * m) + 6 * D * n * m) + 2 * D * D * (n + m) + 2 * D * n * m
+
+
+def cpu_baseline(sd, n, m, budget_s=10.0, max_pairs=8):
+    """Time the numpy oracle (a port of the reference's CPU fp32 path) on this host."""
+    from oracle import lightglue_oracle as O  # test/baseline infrastructure only
+
+    from threadpoolctl import threadpool_limits
+
+    conf = O.make_conf(depth_confidence=-1, width_confidence=-1)
+    # pick the BLAS thread count that is fastest on this host (more threads is not monotonically better
+    # for 1024x256-sized GEMMs); one untimed probe pair per candidate
+    ncpu = os.cpu_count() or 1
+    best, best_t = 1, float("inf")
+    probe = synthetic.make_batch(999, 1, n, m)
+    for th in sorted({1, min(8, ncpu), min(16, ncpu), min(32, ncpu)}):
+        with threadpool_limits(limits=th):
+            t0 = time.perf_counter(); O.forward(sd, conf, probe); t = time.perf_counter() - t0
+        if t < best_t:
+            best, best_t = th, t
+    done, t0 = 0, time.perf_counter()
+    with threadpool_limits(limits=best):
+        while done < max_pairs:
+            data = synthetic.make_batch(1000 + done, 1, n, m)
+            O.forward(sd, conf, data)
+            done += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "image-pairs/s", "cores": best, "kind": "port",
+            "sample": f"{done} pair(s) N=M={n}, 9 layers, fp32 numpy/OpenBLAS port of the reference CPU path, {dt:.1f}s, "
+                      f"{best} BLAS thread(s) (fastest of 1/8/16/32 on {ncpu} logical cores)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp16", "fp32"])
+    ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per step")
+    ap.add_argument("--kpts", type=int, default=N_KPTS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    n = m = args.kpts
+    B = args.pairs
+    sd = synthetic.make_state_dict(0, recipe="A")
+    model = LightGlue(features=None, depth_confidence=-1, width_confidence=-1, precision=args.precision).eval()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    data_np = synthetic.make_batch(1 + rank * B, B, n, m)
+    data = {k: {kk: torch.from_numpy(vv).to(dev) for kk, vv in v.items()} for k, v in data_np.items()}
+    model.reserve(B, n, m, dev)
+    sharded = PairShardedMatcher(model) if world > 1 else None
+
+    def step():
+        if sharded is not None:
+            return sharded.forward_local(data, B * world)
+        return model(data)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        out = step()
+    model.profile(True, dev)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = model.profile_read(dev)
+    model.profile(False, dev)
+
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_pairs = B * world * args.steps
+        value = total_pairs / dt
+        fl = flops_per_launch(B, n, m)
+        timed = {k: v for k, v in prof.items() if v[1] > 0}
+        dom = max((k for k in timed if k in fl), key=lambda k: timed[k][0])
+        dom_ms = timed[dom][0] / timed[dom][1]
+        achieved = fl[dom] / (dom_ms * 1e-3) / 1e12
+        peak = 157.3 if args.precision == "fp32" else 2500.0  # dense MFMA peak, MI355X_MICROARCH.md
+        kernel_ms = {k: round(v[0] / args.steps, 4) for k, v in timed.items()}
+        res = {
+            "metric": "image-pairs/s at N=M=1024, 9 layers; match-index parity vs ref",
+            "value": value,
+            "unit": "image-pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": {"bf16x3": "bf16", "bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.precision],
+            "data": "synthetic",
+            "config": {"workload": f"SuperPoint-dim 256-d descriptors, N=M={n}, 9 layers, pruning/early-stop OFF, batch={B} pairs per GPU, "
+                                   f"seeded random weights (recipe A), precision={args.precision}"
+                                   + (" (split-bf16 MFMA x3 for linear layers + f16 attention, fp32 accumulate/residual)" if args.precision == "bf16x3" else ""),
+                       "pairs_per_gpu": B, "keypoints": n, "parallelism": f"pair-sharded dp{world}"},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None, "avg_launch_ms": dom_ms, "algorithmic_flops_per_launch": fl[dom],
+                         "note": "algorithmic FLOPs (2/MAC) of one launch / HIP-event launch duration; split-bf16 issues 3 MFMAs per algorithmic MAC"},
+            "kernel_ms_per_step": kernel_ms,
+            "gpu_ms_per_step_sum": round(sum(kernel_ms.values()), 3),
+            "algorithmic_tflops": value * flops_per_pair(n, m) / 1e12,
+            "matches_per_pair": float(np.mean([(o > -1).sum().item() for o in out["matches0"]])) if "matches0" in out else None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sd, n, m)
+        print(json.dumps(res))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

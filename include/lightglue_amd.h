@@ -108,6 +108,13 @@ int lg_engine_debug_read(lg_engine* e, const char* name, void* host_dst, int64_t
 /* Row capacities chosen for the last forward (multiples of 128) -> global row = pair*(cap0+cap1) + image*cap0 + r */
 int lg_engine_debug_caps(lg_engine* e, int32_t* cap0, int32_t* cap1);
 
+/* ---- per-kernel-class timing with HIP events on the caller's stream (bench.py roofline leg) ---- */
+int32_t lg_profile_num_classes(void);
+const char* lg_profile_class_name(int32_t cls);
+int lg_engine_profile_enable(lg_engine* e, int32_t on);
+/* Accumulated milliseconds and launch-site counts per class since the last read (resets). */
+int lg_engine_profile_read(lg_engine* e, double* ms, int64_t* count, int32_t n_classes);
+
 #ifdef __cplusplus
 }
 #endif

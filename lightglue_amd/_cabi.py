@@ -21,6 +21,7 @@ EXPORTED_SYMBOLS = (
     "lg_last_error", "lg_version", "lg_engine_create", "lg_engine_destroy", "lg_engine_set_weight",
     "lg_engine_finalize_weights", "lg_engine_reserve", "lg_engine_forward",
     "lg_engine_debug_stop_after", "lg_engine_debug_read", "lg_engine_debug_caps",
+    "lg_profile_num_classes", "lg_profile_class_name", "lg_engine_profile_enable", "lg_engine_profile_read",
 )
 
 
@@ -79,6 +80,11 @@ def load() -> C.CDLL:
     lib.lg_engine_debug_stop_after.argtypes = [C.c_void_p, C.c_int32]
     lib.lg_engine_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     lib.lg_engine_debug_caps.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.lg_profile_num_classes.restype = C.c_int32
+    lib.lg_profile_class_name.restype = C.c_char_p
+    lib.lg_profile_class_name.argtypes = [C.c_int32]
+    lib.lg_engine_profile_enable.argtypes = [C.c_void_p, C.c_int32]
+    lib.lg_engine_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]
     _lib = lib
     return lib
 

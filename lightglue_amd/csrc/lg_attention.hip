@@ -52,11 +52,15 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
     char* smK = smem;
     char* smV = smem + 64 * ROWB;
 
-    const TileLoc t = locate_tile(a.rs, blockIdx.x, ABM);
+    // XCD-aware order: the query tiles of one (segment, head) share its K/V (<= 1 MB at n = 4096), so keep
+    // them consecutive on one XCD's L2; v = (row tile, head) with head fastest-but-one.
+    const int ntile = gridDim.x >> 2;
+    const int v = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = v / ntile;
+    const TileLoc t = locate_tile(a.rs, v - head * ntile, ABM);
     const int qlen = a.rs.len[t.seg];
     if (t.r0 >= qlen) return;
     if (a.rs.active && !a.rs.active[t.pair]) return;
-    const int head = blockIdx.y;
     const int kvseg = a.cross ? (t.seg ^ 1) : t.seg;
     const int kvlen = a.rs.len[kvseg];
     const long long kvbase = seg_row_base(a.rs, kvseg);
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
 
 template <class Tag> static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t s) {
     const int R = a.rs.B * (a.rs.cap0 + a.rs.cap1);
-    dim3 grid(R / ABM, 4);
+    dim3 grid((R / ABM) * 4);
     constexpr int smem = 2 * 64 * 64 * (int)sizeof(typename Tag::elem);
     hipLaunchKernelGGL(attn_kernel<Tag>, grid, dim3(ATHREADS), smem, s, a);
     return hipGetLastError();

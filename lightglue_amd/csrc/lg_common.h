@@ -120,6 +120,14 @@ __device__ __forceinline__ int seg_row_base(const RowSpace& rs, int seg) {
     return (seg >> 1) * (rs.cap0 + rs.cap1) + (seg & 1) * rs.cap0;
 }
 
+// ---- XCD-aware workgroup order.  The dispatcher places workgroup b on XCD b % 8 (observed, used for
+// L2 locality only — never for correctness).  Bijective for any grid size (guide §5 "XCD swizzle must
+// be bijective"): XCD x owns the virtual ids [start(x), start(x) + count(x)).
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, k = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 // ---- wave helpers (wave = 64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -15,6 +15,12 @@
 
 using namespace lg;
 
+// kernel classes for lg_engine_profile_read
+enum { PC_PREP = 0, PC_GEMM_QKV_SELF, PC_ATTN_SELF, PC_GEMM_OUT, PC_GEMM_FFN1, PC_LN_GELU, PC_GEMM_FFN2, PC_GEMM_QKV_CROSS,
+       PC_ATTN_CROSS, PC_ADAPTIVE, PC_ROWDOT, PC_GEMM_FINAL, PC_SIM, PC_ASSIGN, LG_PROF_NCLS };
+static const char* const kProfNames[LG_PROF_NCLS] = {"prep", "gemm_qkv_self", "attn_self", "gemm_out_proj", "gemm_ffn0", "ln_gelu", "gemm_ffn3_resid",
+    "gemm_qkv_cross", "attn_cross", "adaptive", "rowdot", "gemm_final_proj", "sim", "assign"};
+
 namespace {
 
 thread_local std::string g_err = "";
@@ -90,6 +96,13 @@ struct lg_engine {
     void *Q, *K, *VT;
     int *IND, *DST, *LEN, *LEN_OLD, *ACTIVE, *FINAL_LAYER, *ARG0, *ARG1;
     int debug_stop = -1;
+    // ---- per-kernel-class HIP-event timing (bench.py roofline leg)
+    bool profiling = false;
+    struct ProfSpan { hipEvent_t a, b; int cls; };
+    std::vector<ProfSpan> prof_pool;   // events, reused
+    size_t prof_used = 0;
+    double prof_ms[LG_PROF_NCLS] = {0};
+    long long prof_cnt[LG_PROF_NCLS] = {0};
 };
 
 namespace {
@@ -189,9 +202,54 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
     return LG_OK;
 }
 
+int prof_begin(lg_engine* e, int cls, hipStream_t s) {
+    if (!e->profiling) return LG_OK;
+    if (e->prof_used == e->prof_pool.size()) {
+        lg_engine::ProfSpan sp{};
+        HIPCHK(hipEventCreate(&sp.a)); HIPCHK(hipEventCreate(&sp.b));
+        e->prof_pool.push_back(sp);
+    }
+    e->prof_pool[e->prof_used].cls = cls;
+    HIPCHK(hipEventRecord(e->prof_pool[e->prof_used].a, s));
+    return LG_OK;
+}
+int prof_end(lg_engine* e, hipStream_t s) {
+    if (!e->profiling) return LG_OK;
+    HIPCHK(hipEventRecord(e->prof_pool[e->prof_used].b, s));
+    e->prof_used++;
+    return LG_OK;
+}
+int prof_collect(lg_engine* e) {
+    for (size_t i = 0; i < e->prof_used; ++i) {
+        HIPCHK(hipEventSynchronize(e->prof_pool[i].b));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e->prof_pool[i].a, e->prof_pool[i].b));
+        e->prof_ms[e->prof_pool[i].cls] += ms;
+        e->prof_cnt[e->prof_pool[i].cls] += 1;
+    }
+    e->prof_used = 0;
+    return LG_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int32_t lg_profile_num_classes(void) { return LG_PROF_NCLS; }
+const char* lg_profile_class_name(int32_t cls) { return (cls >= 0 && cls < LG_PROF_NCLS) ? kProfNames[cls] : ""; }
+int lg_engine_profile_enable(lg_engine* e, int32_t on) {
+    if (!e) return fail(LG_ERR_INVALID, "null engine");
+    if (!on && e->profiling) { int rc = prof_collect(e); if (rc != LG_OK) return rc; }
+    e->profiling = on != 0;
+    return LG_OK;
+}
+int lg_engine_profile_read(lg_engine* e, double* ms, int64_t* count, int32_t n) {
+    if (!e || !ms || !count || n < LG_PROF_NCLS) return fail(LG_ERR_INVALID, "bad argument");
+    int rc = prof_collect(e);
+    if (rc != LG_OK) return rc;
+    for (int i = 0; i < LG_PROF_NCLS; ++i) { ms[i] = e->prof_ms[i]; count[i] = e->prof_cnt[i]; e->prof_ms[i] = 0; e->prof_cnt[i] = 0; }
+    return LG_OK;
+}
 
 const char* lg_last_error(void) { return g_err.c_str(); }
 const char* lg_version(void) { return "lightglue_amd 0.1 (gfx950)"; }
@@ -415,6 +473,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
         p.Wr = e->Wr; p.pos_dim = 2 + 2 * (e->cfg.add_scale_ori ? 1 : 0);
         p.desc0 = io->desc0; p.desc1 = io->desc1; p.input_dim = e->cfg.input_dim;
         p.X = e->X; p.Xin = e->XIN; p.cosb = e->COS; p.sinb = e->SIN; p.ind = e->IND; p.bbox = e->BBOX;
+        TRY(prof_begin(e, PC_PREP, s));
         HIPCHK(launch_prep(p, s));
     }
     auto gemm = [&](int epi, const RowSpace& rs, const float* A, int lda, const float* A2, int lda2, int K1, int K,
@@ -428,6 +487,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
         GemmArgs g = gemm(EPI_STORE, rs_all, e->XIN, e->cfg.input_dim, nullptr, 0, e->cfg.input_dim, e->cfg.input_dim, e->w_in, e->b_in, D, e->X, D, 1.f);
         HIPCHK(launch_gemm(prec, EPI_STORE, ap, g, s));
     }
+    TRY(prof_end(e, s));
     STEP_DONE();
     const float scale_log2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
 
@@ -438,36 +498,48 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                                       : gemm(EPI_QKV, rs_act, e->X, D, nullptr, 0, D, D, woff(e->w_cqkv, (size_t)i * 512 * D), e->b_cqkv + (size_t)i * 512, 512, nullptr, 0, 1.f);
                 g.q = e->Q; g.k = e->K; g.vt = e->VT; g.n_qk_groups = blk == 0 ? 2 : 1;
                 g.cosb = blk == 0 ? e->COS : nullptr; g.sinb = blk == 0 ? e->SIN : nullptr;
+                TRY(prof_begin(e, blk == 0 ? PC_GEMM_QKV_SELF : PC_GEMM_QKV_CROSS, s));
                 HIPCHK(launch_gemm(prec, EPI_QKV, ap, g, s));
+                TRY(prof_end(e, s));
             }
             STEP_DONE();
             {
                 AttnArgs at{};
                 at.rs = rs_act; at.q = e->Q; at.k = e->K; at.vt = e->VT; at.ctx = e->CTX; at.R = R; at.cross = blk; at.scale_log2e = scale_log2e;
+                TRY(prof_begin(e, blk == 0 ? PC_ATTN_SELF : PC_ATTN_CROSS, s));
                 HIPCHK(launch_attention(ap, at, s));
+                TRY(prof_end(e, s));
             }
             STEP_DONE();
             {
                 GemmArgs g = gemm(EPI_STORE, rs_act, e->CTX, D, nullptr, 0, D, D, woff(blk ? e->w_cout : e->w_sout, (size_t)i * D * D),
                                   (blk ? e->b_cout : e->b_sout) + (size_t)i * D, D, e->MSG, D, 1.f);
+                TRY(prof_begin(e, PC_GEMM_OUT, s));
                 HIPCHK(launch_gemm(prec, EPI_STORE, ap, g, s));
+                TRY(prof_end(e, s));
             }
             STEP_DONE();
             {
                 GemmArgs g = gemm(EPI_STORE, rs_act, e->X, D, e->MSG, D, D, 512, woff(blk ? e->w_cf1 : e->w_sf1, (size_t)i * 512 * 512),
                                   (blk ? e->b_cf1 : e->b_sf1) + (size_t)i * 512, 512, e->H1, 512, 1.f);
+                TRY(prof_begin(e, PC_GEMM_FFN1, s));
                 HIPCHK(launch_gemm(prec, EPI_STORE, ap, g, s));
+                TRY(prof_end(e, s));
             }
             STEP_DONE();
             {
                 LnGeluArgs ln{rs_act, e->H1, e->G, (blk ? e->ln_c_g : e->ln_s_g) + (size_t)i * 512, (blk ? e->ln_c_b : e->ln_s_b) + (size_t)i * 512, R};
+                TRY(prof_begin(e, PC_LN_GELU, s));
                 HIPCHK(launch_ln_gelu(ln, s));
+                TRY(prof_end(e, s));
             }
             STEP_DONE();
             {
                 GemmArgs g = gemm(EPI_RESID, rs_act, e->G, 512, nullptr, 0, 512, 512, woff(blk ? e->w_cf2 : e->w_sf2, (size_t)i * D * 512),
                                   (blk ? e->b_cf2 : e->b_sf2) + (size_t)i * D, D, e->X, D, 1.f);
+                TRY(prof_begin(e, PC_GEMM_FFN2, s));
                 HIPCHK(launch_gemm(prec, EPI_RESID, ap, g, s));
+                TRY(prof_end(e, s));
             }
             STEP_DONE();
         }
@@ -483,7 +555,9 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
             } else {
                 rd.w0 = e->w_match + (size_t)i * D; rd.b0 = e->b_match + i; rd.out0 = e->MSCORE; rd.act0 = 1;
             }
+            TRY(prof_begin(e, PC_ROWDOT, s));
             HIPCHK(launch_rowdot(rd, s));
+            TRY(prof_end(e, s));
             AdaptArgs ad{};
             ad.rs = rs_act; ad.len = e->LEN; ad.active = e->ACTIVE; ad.len_old = e->LEN_OLD; ad.final_layer = e->FINAL_LAYER;
             ad.ind = e->IND; ad.dst = e->DST; ad.prune0 = io->prune0; ad.prune1 = io->prune1; ad.n0 = n0; ad.n1 = n1;
@@ -495,7 +569,9 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
             ad.width_conf = (float)(1.0 - e->cfg.width_confidence);
             ad.pruning_min_kpts = e->cfg.pruning_min_kpts;
             ad.do_stop = do_stop; ad.do_prune = do_prune;
+            TRY(prof_begin(e, PC_ADAPTIVE, s));
             HIPCHK(launch_adapt(ad, s));
+            TRY(prof_end(e, s));
         }
     }
     // ---- log assignment with the weights of the layer each pair stopped at (ref :591)
@@ -503,18 +579,26 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
         RowDotArgs rd{};
         rd.rs = rs_all; rd.X = e->X; rd.w0 = e->w_match; rd.b0 = e->b_match; rd.out0 = e->LS; rd.act0 = 2;
         rd.layer_of_pair = e->FINAL_LAYER; rd.w_layer_stride = D; rd.ignore_active = 1;
+        TRY(prof_begin(e, PC_ROWDOT, s));
         HIPCHK(launch_rowdot(rd, s));
+        TRY(prof_end(e, s));
         GemmArgs g = gemm(EPI_STORE, rs_all, e->X, D, nullptr, 0, D, D, e->w_final, e->b_final, D, e->MD, D, 0.25f);  // ref :291: / d**0.25
         g.layer_of_pair = e->FINAL_LAYER; g.w_layer_stride = (long long)D * D; g.b_layer_stride = D;
+        TRY(prof_begin(e, PC_GEMM_FINAL, s));
         HIPCHK(launch_gemm(prec, EPI_STORE, ap, g, s));
+        TRY(prof_end(e, s));
         SimArgs sm{rs_all, e->MD, D, D, e->SIM};
+        TRY(prof_begin(e, PC_SIM, s));
         HIPCHK(launch_sim(prec, sm, s));
+        TRY(prof_end(e, s));
         AssignArgs as{};
         as.rs = rs_all; as.sim = e->SIM; as.ls = e->LS; as.lse_r = e->LSE_R; as.lse_c = e->LSE_C; as.max0 = e->MAX0; as.arg0 = e->ARG0;
         as.max1 = e->MAX1; as.arg1 = e->ARG1; as.ind = e->IND; as.n0 = n0; as.n1 = n1; as.filter_threshold = (float)e->cfg.filter_threshold;
         as.m0 = io->matches0; as.m1 = io->matches1; as.s0 = io->scores0; as.s1 = io->scores1;
         as.matches = io->matches; as.mscores = io->match_scores; as.n_matches = io->n_matches; as.max_matches = max_matches;
+        TRY(prof_begin(e, PC_ASSIGN, s));
         HIPCHK(launch_assign(as, s));
+        TRY(prof_end(e, s));
         hipLaunchKernelGGL(write_stop_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, e->FINAL_LAYER, io->stop);
         HIPCHK(hipGetLastError());
     }

@@ -157,10 +157,15 @@ template <> __device__ __forceinline__ f16_t cvt_out<f16_t>(float x) { return (f
 template <int PREC, int EPI, class TA>
 __global__ __launch_bounds__(GTHREADS) void gemm_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const TileLoc t = locate_tile(a.rs, blockIdx.x, GBM);
+    // XCD-aware tile order (guide T1): workgroup id b runs on XCD b % 8, so give every XCD a contiguous
+    // range of virtual ids, column tiles fastest -> the Nout/128 workgroups that re-read one 128-row A
+    // tile run back-to-back on ONE XCD and hit its L2 instead of going to HBM Nout/128 times.
+    const int ncol = a.Nout / GBN;
+    const int v = xcd_remap(blockIdx.x, gridDim.x);
+    const TileLoc t = locate_tile(a.rs, v / ncol, GBM);
     if (t.r0 >= a.rs.len[t.seg]) return;
     if (a.rs.active && !a.rs.active[t.pair]) return;
-    const int n0 = blockIdx.y * GBN;
+    const int n0 = (v % ncol) * GBN;
     const char* W = static_cast<const char*>(a.W);
     const char* Wlo = static_cast<const char*>(a.Wlo);
     const float* bias = a.bias;
@@ -271,7 +276,7 @@ template <int PREC> static constexpr int smem_bytes() { return 2 * PT<PREC>::NPA
 template <int PREC, int EPI, class TA>
 static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
     const int R = a.rs.B * (a.rs.cap0 + a.rs.cap1);
-    dim3 grid(R / GBM, a.Nout / GBN);
+    dim3 grid((R / GBM) * (a.Nout / GBN));
     auto kern = gemm_kernel<PREC, EPI, TA>;
     constexpr int smem = smem_bytes<PREC>();
     if (smem > 64 * 1024) {

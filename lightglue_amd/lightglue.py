@@ -324,6 +324,9 @@ class LightGlue(nn.Module):
             stream = torch.cuda.current_stream(device).cuda_stream
             _cabi.check(_cabi.load().lg_engine_forward(handle, C.byref(io), C.c_void_p(stream)))
 
+        if getattr(self, "_debug_step", -1) >= 0:  # test tap: the pipeline stopped early, outputs are not written
+            torch.cuda.synchronize(device)
+            return None
         # ---- output assembly (ref :593-629)
         counts = n_matches.tolist()  # the one host synchronisation of the forward (ragged lists need sizes)
         matches = [mlist[k, : counts[k]].long() for k in range(b)]
@@ -349,10 +352,25 @@ class LightGlue(nn.Module):
             "prune1": prune1,
         }
 
+    # ------------------------------------------------------------------ per-kernel timing (HIP events)
+    def profile(self, enable: bool, device="cuda"):
+        h = self._get_engine(torch.device(device))
+        _cabi.check(_cabi.load().lg_engine_profile_enable(h, int(bool(enable))))
+
+    def profile_read(self, device="cuda") -> dict:
+        """{kernel class: (total ms, launch sites)} accumulated since the last read."""
+        h = self._get_engine(torch.device(device))
+        lib = _cabi.load()
+        n = lib.lg_profile_num_classes()
+        ms, cnt = (C.c_double * n)(), (C.c_int64 * n)()
+        _cabi.check(lib.lg_engine_profile_read(h, ms, cnt, n))
+        return {lib.lg_profile_class_name(i).decode(): (ms[i], cnt[i]) for i in range(n)}
+
     # ------------------------------------------------------------------ test / profiling taps
     def debug_stop_after(self, step: int, device="cuda"):
         h = self._get_engine(torch.device(device))
         _cabi.check(_cabi.load().lg_engine_debug_stop_after(h, int(step)))
+        self._debug_step = int(step)
 
     def debug_read(self, name: str, dtype=np.float32, device="cuda") -> np.ndarray:
         h = self._get_engine(torch.device(device))

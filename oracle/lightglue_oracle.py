@@ -117,7 +117,14 @@ class _Ctx:
     def mm(self, a, b, where="lin"):
         """a @ b with optional operand rounding; accumulation in ``dtype``."""
         r = _ROUNDERS[self.quant.get(where)]
-        return np.matmul(r(a), r(b))
+        a, b = r(a), r(b)
+        # BLAS needs a unit stride in one of the last two axes; the q/k/v views of the interleaved Wqkv
+        # output (ref :166-167) have stride 3 and would fall back to numpy's slow generic loop
+        if a.ndim >= 2 and a.strides[-1] != a.itemsize and a.strides[-2] != a.itemsize:
+            a = np.ascontiguousarray(a)
+        if b.ndim >= 2 and b.strides[-1] != b.itemsize and b.strides[-2] != b.itemsize:
+            b = np.ascontiguousarray(b)
+        return np.matmul(a, b)
 
     def linear(self, x, w, b=None, where="lin"):
         """nn.Linear: x @ w.T + b"""

@@ -1,0 +1,64 @@
+"""The C-ABI library loads on a box without a GPU and exports every symbol include/lightglue_amd.h
+declares (no compute calls here)."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+from lightglue_amd import _cabi
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = (ROOT / "include" / "lightglue_amd.h").read_text()
+
+
+def declared_functions():
+    # prototypes look like:  <ret> lg_xxx(...);
+    return sorted(set(re.findall(r"\b(lg_[a-z_]+)\s*\(", HEADER)))
+
+
+def test_library_is_built():
+    assert _cabi.library_path().exists(), "run __graft_entry__.build() first"
+
+
+def test_exports_every_declared_symbol():
+    lib = _cabi.load()
+    names = declared_functions()
+    assert set(names) == set(_cabi.EXPORTED_SYMBOLS), (names, _cabi.EXPORTED_SYMBOLS)
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
+def test_struct_layouts_match_header():
+    # field order of the ctypes mirrors == order of the declarations in the header
+    def fields_of(struct_name):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct_name, struct_name), HEADER, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = decl.split(None, 1)[1] if not decl.startswith("const") else decl.split(None, 2)[2]
+            out += [n.strip().lstrip("*") for n in names.split(",")]
+        return out
+    assert fields_of("lg_config") == [f[0] for f in _cabi.LgConfig._fields_]
+    assert fields_of("lg_forward_io") == [f[0] for f in _cabi.LgForwardIO._fields_]
+
+
+def test_argument_validation_without_gpu():
+    lib = _cabi.load()
+    assert lib.lg_version().decode().startswith("lightglue_amd")
+    h = ctypes.c_void_p()
+    bad = _cabi.LgConfig(256, 128, 9, 4, 0, 0.95, 0.99, 0.1, -1, 3, -1)  # descriptor_dim != 256
+    assert lib.lg_engine_create(ctypes.byref(bad), ctypes.byref(h)) == _cabi.LG_ERR_INVALID
+    assert b"descriptor_dim" in lib.lg_last_error()
+    with pytest.raises(AssertionError):
+        _cabi.check(_cabi.LG_ERR_INVALID)
+    ok = _cabi.LgConfig(256, 256, 9, 4, 0, 0.95, 0.99, 0.1, -1, 3, -1)
+    assert lib.lg_engine_create(ctypes.byref(ok), ctypes.byref(h)) == _cabi.LG_OK
+    # forward before weights -> state error, no GPU touched
+    io = _cabi.LgForwardIO()
+    io.batch, io.n0, io.n1 = 1, 4, 4
+    assert lib.lg_engine_forward(h, ctypes.byref(io), None) == _cabi.LG_ERR_STATE
+    lib.lg_engine_destroy(h)

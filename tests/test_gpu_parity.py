@@ -1,0 +1,98 @@
+"""GPU parity: the HIP path (through the public class -> ctypes -> C ABI) against the golden vectors
+of the real reference and against the oracle.  Bar (BASELINE.json): indices bit-identical, scores
+within 1e-3.  "fp32" (exact f32 MFMA) must match everywhere; the default "bf16x3" (split-bf16 linear
+layers + f16 attention) must match except where the oracle sits within tolerance of a decision
+boundary, proven per element by conftest.explain_mismatches."""
+import numpy as np
+import pytest
+import torch
+
+import gpu_util
+import make_golden
+from conftest import SCORE_TOL, explain_mismatches, golden_names, load_golden, oracle_conf_for, require_gpu
+from lightglue_amd import synthetic as synth
+from oracle import lightglue_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def run_case(name, precision):
+    meta, gold = load_golden(name)
+    case = meta["case"]
+    sd, data = make_golden.case_inputs(case)
+    kw = dict(case["conf"])
+    if "prune_th" in case:
+        kw["pruning_min_kpts"] = case["prune_th"]
+    model = gpu_util.make_model(sd, precision, **kw)
+    out = model(gpu_util.to_torch(data))
+    torch.cuda.synchronize()
+    return case, sd, data, gold, out
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_fp32_mode_matches_golden_exactly(name):
+    require_gpu()
+    case, sd, data, gold, out = run_case(name, "fp32")
+    np.testing.assert_array_equal(out["matches0"].cpu().numpy(), gold["matches0"])
+    np.testing.assert_array_equal(out["matches1"].cpu().numpy(), gold["matches1"])
+    np.testing.assert_allclose(out["matching_scores0"].cpu().numpy(), gold["matching_scores0"], atol=2e-4, rtol=0)
+    np.testing.assert_allclose(out["matching_scores1"].cpu().numpy(), gold["matching_scores1"], atol=2e-4, rtol=0)
+    stop = out["stop"] if not torch.is_tensor(out["stop"]) else out["stop"].cpu().tolist()
+    assert np.atleast_1d(stop).tolist() == gold["stop"].tolist()
+    np.testing.assert_array_equal(out["prune0"].cpu().numpy().astype(np.float32), gold["prune0"])
+    np.testing.assert_array_equal(out["prune1"].cpu().numpy().astype(np.float32), gold["prune1"])
+    # output dict contract (ref :619-629)
+    assert out["matches0"].dtype == torch.int64 and out["matching_scores0"].dtype == torch.float32
+    assert [int(x.shape[0]) for x in out["matches"]] == gold["n_matches"].tolist()
+    for b, ml in enumerate(out["matches"]):
+        ml = ml.cpu().numpy()
+        assert ml.dtype == np.int64 and (np.diff(ml[:, 0]) > 0).all()          # sorted by index0 (ref :596)
+        np.testing.assert_array_equal(ml[:, 1], gold["matches0"][b][ml[:, 0]])
+    pruning = case["conf"].get("width_confidence", 0.99) > 0
+    assert out["prune0"].dtype == (torch.int64 if pruning else torch.float32)  # ref :535 vs :616
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_default_precision_parity(name):
+    require_gpu()
+    case, sd, data, gold, out = run_case(name, "bf16x3")
+    m0, s0 = out["matches0"].cpu().numpy(), out["matching_scores0"].cpu().numpy()
+    assert np.abs(s0 - gold["matching_scores0"]).max(initial=0.0) <= SCORE_TOL
+    assert np.abs(out["matching_scores1"].cpu().numpy() - gold["matching_scores1"]).max(initial=0.0) <= SCORE_TOL
+    adaptive = case["conf"].get("depth_confidence", 0.95) > 0 or case["conf"].get("width_confidence", 0.99) > 0
+    if (m0 != gold["matches0"]).any():
+        assert not adaptive, "index mismatch on an adaptive case"
+        conf = oracle_conf_for(case)
+        for b in range(m0.shape[0]):
+            tr = {}
+            g = lambda d, k: None if d.get(k) is None else np.asarray(d[k])[b]
+            d0, d1 = data["image0"], data["image1"]
+            ref = O.forward_pair(sd, conf, g(d0, "keypoints"), g(d1, "keypoints"), g(d0, "descriptors"), g(d1, "descriptors"),
+                                 g(d0, "image_size"), g(d1, "image_size"), g(d0, "scales"), g(d0, "oris"), g(d1, "scales"), g(d1, "oris"), trace=tr)
+            un = explain_mismatches(m0[b], s0[b], ref, filter_threshold=conf.filter_threshold, scores_full=tr["scores_full"], ind0=tr["ind0"], ind1=tr["ind1"])
+            assert un == 0, f"{un} unexplained index mismatches in pair {b}"
+    stop = out["stop"] if not torch.is_tensor(out["stop"]) else out["stop"].cpu().tolist()
+    assert np.atleast_1d(stop).tolist() == gold["stop"].tolist()
+    np.testing.assert_array_equal(out["prune0"].cpu().numpy().astype(np.float32), gold["prune0"])
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16x3", 5e-4), ("fp16", 2e-2), ("bf16", 1e-1)])
+def test_pipeline_stages_layer0(precision, tol):
+    """Every kernel of layer 0 against the oracle's intermediate tensors (err relative to rms)."""
+    require_gpu()
+    sd = synth.make_state_dict(0, recipe="A")
+    data = synth.make_batch(7, 2, 200, 160)
+    res = gpu_util.stage_errors(sd, data, precision, dict(depth_confidence=-1, width_confidence=-1))
+    bad = {k: v for k, v in res.items() if not (v[1] <= (tol if not k.startswith(("self.q", "self.k", "self.v", "cross.qk", "cross.v")) else max(tol, {"fp32": 2e-5, "bf16x3": 3e-3, "fp16": 5e-3, "bf16": 5e-2}[precision])))}
+    assert not bad, bad
+
+
+def test_plain_bf16_mismatch_rate_is_reported_not_hidden():
+    """precision='bf16' (single bf16 MFMA everywhere) is the fast mode; it does NOT hold the 1e-3 bar.
+    Assert the documented envelope: <= 2 % index flips, |dscore| <= 0.5."""
+    require_gpu()
+    case, sd, data, gold, out = run_case("nonadaptive_512", "bf16")
+    m0 = out["matches0"].cpu().numpy()
+    flips = (m0 != gold["matches0"]).mean()
+    assert flips <= 0.02, flips
+    assert np.abs(out["matching_scores0"].cpu().numpy() - gold["matching_scores0"]).max() <= 0.5

@@ -1,0 +1,84 @@
+"""Host-side mirror of the reference interface (no GPU): constructor, conf, state-dict contract,
+error behaviour, and the rule that there is no CPU fallback."""
+import numpy as np
+import pytest
+import torch
+
+from lightglue_amd import LightGlue
+from oracle import lightglue_oracle as O
+from lightglue_amd import synthetic as synth
+import make_golden
+
+
+def test_state_dict_names_and_shapes_match_reference_contract():
+    # 252 tensors / 11 851 601 params for SuperPoint; +input_proj for 128-d
+    m = LightGlue(features=None)
+    sd = m.state_dict()
+    spec = synth.state_dict_spec()
+    assert [k for k in sd if k != "confidence_thresholds"] == [n for n, _, _ in spec] or \
+        set(k for k in sd if k != "confidence_thresholds") == set(n for n, _, _ in spec)
+    for n, shape, _ in spec:
+        assert tuple(sd[n].shape) == tuple(shape), n
+    assert sum(p.numel() for p in m.parameters()) == 11_851_601
+    m128 = LightGlue(features=None, input_dim=128, add_scale_ori=True)
+    assert tuple(m128.state_dict()["input_proj.weight"].shape) == (256, 128)
+    assert tuple(m128.state_dict()["posenc.Wr.weight"].shape) == (32, 4)
+
+
+@pytest.mark.skipif(not make_golden.REF.exists(), reason="reference tree not mounted")
+def test_state_dict_interchangeable_with_reference_module():
+    lg = make_golden.load_reference()
+    ref = lg.LightGlue(features=None, input_dim=128)
+    ours = LightGlue(features=None, input_dim=128)
+    assert list(ref.state_dict().keys()) == list(ours.state_dict().keys())
+    res = ours.load_state_dict(ref.state_dict(), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in ref.state_dict().items():
+        assert torch.equal(v, ours.state_dict()[k])
+
+
+def test_default_conf_and_thresholds():
+    m = LightGlue(features=None)
+    for k, v in dict(input_dim=256, descriptor_dim=256, add_scale_ori=False, n_layers=9, num_heads=4, flash=True, mp=False,
+                     depth_confidence=0.95, width_confidence=0.99, filter_threshold=0.1, weights=None).items():
+        assert getattr(m.conf, k) == v
+    np.testing.assert_allclose(m.confidence_thresholds.numpy(), O.confidence_thresholds_f32(9), rtol=0, atol=0)
+    assert m.pruning_min_kpts(torch.device("cuda")) == 1536
+    assert m.pruning_min_kpts(torch.device("cpu")) == -1
+    assert LightGlue(features=None, flash=False).pruning_min_kpts(torch.device("cuda")) == 1024
+    assert LightGlue(features=None, pruning_min_kpts=7).pruning_min_kpts(torch.device("cuda")) == 7
+    assert LightGlue.required_data_keys == ["image0", "image1"]
+
+
+def test_errors_mirror_reference():
+    with pytest.raises(ValueError):
+        LightGlue(features="orb")
+    m = LightGlue(features=None)
+    with pytest.raises(AssertionError):
+        m({"image0": {}})
+    with pytest.raises(ValueError):
+        LightGlue(features=None, precision="int8")
+
+
+def test_feature_presets_select_dims():
+    # released weights cannot be fetched offline: the presets must still resolve dims before loading
+    for name, dim, so in [("superpoint", 256, False), ("disk", 128, False), ("aliked", 128, False), ("sift", 128, True), ("doghardnet", 128, True)]:
+        assert LightGlue.features[name]["input_dim"] == dim
+        assert bool(LightGlue.features[name].get("add_scale_ori", False)) == so
+    with pytest.raises(RuntimeError, match="pretrained weights"):
+        LightGlue(features="disk")
+
+
+def test_no_cpu_fallback():
+    m = LightGlue(features=None)
+    d = {"keypoints": torch.rand(1, 8, 2), "descriptors": torch.rand(1, 8, 256)}
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m({"image0": d, "image1": d})
+
+
+def test_product_code_never_imports_the_oracle():
+    import pathlib
+    pkg = pathlib.Path(__file__).resolve().parent.parent / "lightglue_amd"
+    for f in list(pkg.glob("*.py")) + list((pkg / "csrc").glob("*")):
+        if f.is_file() and f.suffix in (".py", ".hip", ".h"):
+            assert "oracle" not in f.read_text().replace("no CPU / PyTorch fallback", ""), f

@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 
 from conftest import golden_names, load_golden, oracle_conf_for
-from oracle import lightglue_oracle as O, synth
+from oracle import lightglue_oracle as O
+from lightglue_amd import synthetic as synth
 import make_golden
 
 

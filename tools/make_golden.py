@@ -21,7 +21,7 @@ import torch
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-from oracle import synth  # noqa: E402
+from lightglue_amd import synthetic as synth  # noqa: E402
 
 REF = Path("/root/reference/lightglue/lightglue.py")
 

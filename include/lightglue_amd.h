@@ -95,6 +95,10 @@ int lg_engine_reserve(lg_engine* e, int32_t max_batch, int32_t max_n0, int32_t m
  * Asynchronous: no host synchronisation when the workspace is already large enough. */
 int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream);
 
+/* Engine options.  "fused_tail" (default 1): run out_proj + ffn + LayerNorm + GELU + residual as one kernel
+ * (lg_tail.hip); 0 selects the unfused per-layer kernels (kept for stage-by-stage parity tests). */
+int lg_engine_set_option(lg_engine* e, const char* key, int32_t value);
+
 /* ---- test / profiling taps (not used by the product path) ---- */
 /* Stop the next forwards after pipeline step `step` (-1 = run everything).  Step numbering:
  * 0 = prep (+input projection); 1 + 12*layer + k, k = 0 self-QKV, 1 self-attention, 2 out_proj,

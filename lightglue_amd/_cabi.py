@@ -19,7 +19,7 @@ LG_FLAG_NO_PRUNING = 1
 # every symbol include/lightglue_amd.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (
     "lg_last_error", "lg_version", "lg_engine_create", "lg_engine_destroy", "lg_engine_set_weight",
-    "lg_engine_finalize_weights", "lg_engine_reserve", "lg_engine_forward",
+    "lg_engine_finalize_weights", "lg_engine_reserve", "lg_engine_forward", "lg_engine_set_option",
     "lg_engine_debug_stop_after", "lg_engine_debug_read", "lg_engine_debug_caps",
     "lg_profile_num_classes", "lg_profile_class_name", "lg_engine_profile_enable", "lg_engine_profile_read",
 )
@@ -77,6 +77,7 @@ def load() -> C.CDLL:
     lib.lg_engine_finalize_weights.argtypes = [C.c_void_p]
     lib.lg_engine_reserve.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.lg_engine_forward.argtypes = [C.c_void_p, C.POINTER(LgForwardIO), C.c_void_p]
+    lib.lg_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
     lib.lg_engine_debug_stop_after.argtypes = [C.c_void_p, C.c_int32]
     lib.lg_engine_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     lib.lg_engine_debug_caps.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]

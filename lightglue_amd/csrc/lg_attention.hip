@@ -104,14 +104,23 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
         }
     };
     auto store_tile = [&](int kv0) {
+        if (kv0 + ABK <= kvlen) {   // wave-uniform fast path: every key of the tile is live
 #pragma unroll
-        for (int i = 0; i < NCT; ++i) {
-            const int c = tid + ATHREADS * i, row = c / SLOTS, slot = c % SLOTS;
-            // rows/keys past the live length may hold anything (uninitialised workspace): zero them so
-            // that 0-probabilities never multiply a NaN
-            const u32x4 kz = (kv0 + row < kvlen) ? rk[i] : u32x4{0u, 0u, 0u, 0u};
-            *reinterpret_cast<u32x4*>(smK + lds_off<ROWB>(row, slot)) = kz;
-            *reinterpret_cast<u32x4*>(smV + lds_off<ROWB>(row, slot)) = mask_tail<Tag>(rv[i], kvlen - (kv0 + slot * EPC));
+            for (int i = 0; i < NCT; ++i) {
+                const int c = tid + ATHREADS * i, row = c / SLOTS, slot = c % SLOTS;
+                *reinterpret_cast<u32x4*>(smK + lds_off<ROWB>(row, slot)) = rk[i];
+                *reinterpret_cast<u32x4*>(smV + lds_off<ROWB>(row, slot)) = rv[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NCT; ++i) {
+                const int c = tid + ATHREADS * i, row = c / SLOTS, slot = c % SLOTS;
+                // rows/keys past the live length may hold anything (uninitialised workspace): zero them so
+                // that 0-probabilities never multiply a NaN
+                const u32x4 kz = (kv0 + row < kvlen) ? rk[i] : u32x4{0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4*>(smK + lds_off<ROWB>(row, slot)) = kz;
+                *reinterpret_cast<u32x4*>(smV + lds_off<ROWB>(row, slot)) = mask_tail<Tag>(rv[i], kvlen - (kv0 + slot * EPC));
+            }
         }
     };
 
@@ -137,37 +146,51 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
                 mma_chunk<Tag>(s[kt][1], kf, qf[1][c]);
             }
         }
-        // ---- online softmax (fp32), per query column
-        const bool tail = kv0 + ABK > kvlen;
+        // ---- online softmax (fp32), per query column.  Only the last tile can hold dead keys.
+        if (kv0 + ABK > kvlen) {   // wave-uniform
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kv0 + kt * 16 + g * 4 + r >= kvlen) s[kt][qt][r] = -INFINITY;
+        }
+        float m_new[2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            float mx = -INFINITY;
+            float mx = fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3]));
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = s[kt][qt][r] * a.scale_log2e;
-                    if (tail && kv0 + kt * 16 + g * 4 + r >= kvlen) v = -INFINITY;
-                    s[kt][qt][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+            for (int kt = 1; kt < 4; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(s[kt][qt][0], s[kt][qt][1]), fmaxf(s[kt][qt][2], s[kt][qt][3])));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[qt], mx);   // finite: every tile holds >= 1 live key
-            const float alpha = exp2f(m_run[qt] - m_new);
-            m_run[qt] = m_new;
+            m_new[qt] = fmaxf(m_run[qt], mx * a.scale_log2e);   // finite: every tile holds >= 1 live key (scale > 0)
+        }
+        // rescale the running output only when some row's maximum actually moved (exact: alpha == 1
+        // otherwise); keeps the O accumulators untouched by the VALU on most tiles
+        if (__any((m_new[0] != m_run[0]) || (m_new[1] != m_run[1]))) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new[qt]);
+                l_run[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt][qt] *= alpha;
+                m_run[qt] = m_new[qt];
+            }
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
             float rs = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = exp2f(s[kt][qt][r] - m_new);
+                    // exp2(s*c - m): one fma + the bare v_exp_f32 (arguments <= 0, flush-to-zero tail is fine)
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], a.scale_log2e, -m_run[qt]));
                     s[kt][qt][r] = p;
                     rs += p;
                 }
-            l_run[qt] = l_run[qt] * alpha + rs;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt][qt] *= alpha;
+            l_run[qt] += rs;
         }
         // ---- O^T += V^T P^T
         if constexpr (EPC == 8) {

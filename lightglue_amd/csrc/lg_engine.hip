@@ -17,9 +17,9 @@ using namespace lg;
 
 // kernel classes for lg_engine_profile_read
 enum { PC_PREP = 0, PC_GEMM_QKV_SELF, PC_ATTN_SELF, PC_GEMM_OUT, PC_GEMM_FFN1, PC_LN_GELU, PC_GEMM_FFN2, PC_GEMM_QKV_CROSS,
-       PC_ATTN_CROSS, PC_ADAPTIVE, PC_ROWDOT, PC_GEMM_FINAL, PC_SIM, PC_ASSIGN, LG_PROF_NCLS };
+       PC_ATTN_CROSS, PC_ADAPTIVE, PC_ROWDOT, PC_GEMM_FINAL, PC_SIM, PC_ASSIGN, PC_TAIL, LG_PROF_NCLS };
 static const char* const kProfNames[LG_PROF_NCLS] = {"prep", "gemm_qkv_self", "attn_self", "gemm_out_proj", "gemm_ffn0", "ln_gelu", "gemm_ffn3_resid",
-    "gemm_qkv_cross", "attn_cross", "adaptive", "rowdot", "gemm_final_proj", "sim", "assign"};
+    "gemm_qkv_cross", "attn_cross", "adaptive", "rowdot", "gemm_final_proj", "sim", "assign", "fused_tail"};
 
 namespace {
 
@@ -87,6 +87,11 @@ struct lg_engine {
     float *ln_s_g = nullptr, *ln_s_b = nullptr, *ln_c_g = nullptr, *ln_c_b = nullptr;  // [L][512]
     float *w_match = nullptr, *b_match = nullptr, *w_tok = nullptr, *b_tok = nullptr;  // [L][256], [L]
     float* Wr = nullptr;
+    // fused block tail (lg_tail.hip): fragment-packed [Wcat | planes] and W2 per layer, folded bias
+    char *w_stail_cat = nullptr, *w_stail_2 = nullptr, *w_ctail_cat = nullptr, *w_ctail_2 = nullptr;
+    float *b_scat = nullptr, *b_ccat = nullptr;
+    size_t tail_cat_layer_bytes = 0, tail_2_layer_bytes = 0;
+    int fused_tail = 1;
     // ---- workspace
     void* ws = nullptr; size_t ws_bytes = 0;
     int capB = 0, cap0 = 0, cap1 = 0;      // reserved
@@ -126,6 +131,31 @@ int upload_packed(int prec, const float* src, size_t n, PackedW& dst, size_t ele
     }
     HIPCHK(hipMemcpy(static_cast<char*>(dst.hi) + elem_offset * es, hi.data(), n * es, hipMemcpyHostToDevice));
     if (prec == PREC_BF16X3) HIPCHK(hipMemcpy(static_cast<char*>(dst.lo) + elem_offset * es, lo.data(), n * es, hipMemcpyHostToDevice));
+    return LG_OK;
+}
+
+// MFMA-fragment order (lg_kernels.h TailArgs): plane-major, then [n-tile][k-chunk][lane][EPC]
+int upload_fragment_packed(int prec, const std::vector<double>& W, int rows, int K, char* dst) {
+    const size_t es = elem_size(prec);
+    const int EPC = prec == PREC_F32 ? 4 : 8, KC = 4 * EPC, NKC = K / KC, NT = rows / 16;
+    const bool split = prec == PREC_BF16X3;
+    const size_t n = (size_t)rows * K;
+    std::vector<char> buf(n * es * (split ? 2 : 1));
+    for (int nt = 0; nt < NT; ++nt)
+        for (int kc = 0; kc < NKC; ++kc)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < EPC; ++j) {
+                    const float v = (float)W[(size_t)(nt * 16 + (lane & 15)) * K + kc * KC + (lane >> 4) * EPC + j];
+                    const size_t idx = ((size_t)(nt * NKC + kc) * 64 + lane) * EPC + j;
+                    if (prec == PREC_F32) reinterpret_cast<float*>(buf.data())[idx] = v;
+                    else if (prec == PREC_F16) reinterpret_cast<uint16_t*>(buf.data())[idx] = f32_to_f16(v);
+                    else {
+                        const uint16_t h = f32_to_bf16(v);
+                        reinterpret_cast<uint16_t*>(buf.data())[idx] = h;
+                        if (split) reinterpret_cast<uint16_t*>(buf.data())[n + idx] = f32_to_bf16(v - bf16_to_f32(h));
+                    }
+                }
+    HIPCHK(hipMemcpy(dst, buf.data(), buf.size(), hipMemcpyHostToDevice));
     return LG_OK;
 }
 
@@ -306,6 +336,10 @@ int lg_engine_finalize_weights(lg_engine* e) {
     addf((size_t)L * 512); addf((size_t)L * D); addf((size_t)L * 512); addf((size_t)L * D); addf((size_t)L * D);
     for (int i = 0; i < 4; ++i) addf((size_t)L * 512);
     addf((size_t)L * D); addf(L); addf((size_t)L * D); addf(L); addf(32 * 4);
+    const size_t planes = split ? 2 : 1;
+    const size_t cat_layer = (size_t)512 * 512 * es * planes, w2_layer = (size_t)256 * 512 * es * planes;
+    for (int i = 0; i < 2; ++i) { total = ((total + 255) & ~size_t(255)) + L * cat_layer; total = ((total + 255) & ~size_t(255)) + L * w2_layer; }
+    addf((size_t)L * 512); addf((size_t)L * 512);
     total += 4096;
     if (e->w_arena) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(e->w_arena)); e->w_arena = nullptr; }
     HIPCHK(hipMalloc(&e->w_arena, total));
@@ -321,6 +355,10 @@ int lg_engine_finalize_weights(lg_engine* e) {
     e->b_cqkv = takef((size_t)L * 512); e->b_cout = takef((size_t)L * D); e->b_cf1 = takef((size_t)L * 512); e->b_cf2 = takef((size_t)L * D); e->b_final = takef((size_t)L * D);
     e->ln_s_g = takef((size_t)L * 512); e->ln_s_b = takef((size_t)L * 512); e->ln_c_g = takef((size_t)L * 512); e->ln_c_b = takef((size_t)L * 512);
     e->w_match = takef((size_t)L * D); e->b_match = takef(L); e->w_tok = takef((size_t)L * D); e->b_tok = takef(L); e->Wr = takef(32 * 4);
+    e->tail_cat_layer_bytes = cat_layer; e->tail_2_layer_bytes = w2_layer;
+    e->w_stail_cat = static_cast<char*>(ar.take(L * cat_layer)); e->w_stail_2 = static_cast<char*>(ar.take(L * w2_layer));
+    e->w_ctail_cat = static_cast<char*>(ar.take(L * cat_layer)); e->w_ctail_2 = static_cast<char*>(ar.take(L * w2_layer));
+    e->b_scat = takef((size_t)L * 512); e->b_ccat = takef((size_t)L * 512);
 
     std::string err;
     auto up_f32 = [&](float* dst, const float* src, size_t n) -> int { HIPCHK(hipMemcpy(dst, src, n * 4, hipMemcpyHostToDevice)); return LG_OK; };
@@ -365,6 +403,31 @@ int lg_engine_finalize_weights(lg_engine* e) {
             TRY(upload_packed(prec, w3->data.data(), (size_t)D * 512, blk ? e->w_cf2 : e->w_sf2, (size_t)i * D * 512));
             TRY(up_f32((blk ? e->b_cf2 : e->b_sf2) + (size_t)i * D, b3->data.data(), D));
         }
+        for (int blk = 0; blk < 2; ++blk) {   // fused tail: Wcat = [W1x | W1m Wo], bcat = b1 + W1m bo (double precision fold)
+            const std::string& p = blk ? c : s;
+            const HostTensor* w0 = &e->staged[p + "ffn.0.weight"]; const HostTensor* b0 = &e->staged[p + "ffn.0.bias"];
+            const HostTensor* w3 = &e->staged[p + "ffn.3.weight"];
+            std::string oname = blk ? c + "to_out" : s + "out_proj";
+            NEED(wo, oname + ".weight", D, D); NEED(bo, oname + ".bias", D);
+            std::vector<double> cat((size_t)512 * 512), w2d((size_t)256 * 512);
+            std::vector<float> bc(512);
+            for (int n = 0; n < 512; ++n) {
+                const float* w1row = &w0->data[(size_t)n * 512];
+                for (int k = 0; k < 256; ++k) cat[(size_t)n * 512 + k] = w1row[k];
+                double bacc = b0->data[n];
+                for (int j = 0; j < 256; ++j) bacc += (double)w1row[256 + j] * (double)bo->data[j];
+                bc[n] = (float)bacc;
+                for (int k = 0; k < 256; ++k) {
+                    double acc = 0.0;
+                    for (int j = 0; j < 256; ++j) acc += (double)w1row[256 + j] * (double)wo->data[(size_t)j * 256 + k];
+                    cat[(size_t)n * 512 + 256 + k] = acc;
+                }
+            }
+            for (size_t q = 0; q < w2d.size(); ++q) w2d[q] = w3->data[q];
+            TRY(upload_fragment_packed(prec, cat, 512, 512, (blk ? e->w_ctail_cat : e->w_stail_cat) + (size_t)i * cat_layer));
+            TRY(upload_fragment_packed(prec, w2d, 256, 512, (blk ? e->w_ctail_2 : e->w_stail_2) + (size_t)i * w2_layer));
+            TRY(up_f32((blk ? e->b_ccat : e->b_scat) + (size_t)i * 512, bc.data(), 512));
+        }
         {   // cross: [to_qk ; to_v] share one GEMM (both applied to both images, ref :204-205)
             NEED(wq, c + "to_qk.weight", D, D); NEED(bq, c + "to_qk.bias", D);
             NEED(wv, c + "to_v.weight", D, D); NEED(bv, c + "to_v.bias", D);
@@ -402,6 +465,12 @@ int lg_engine_finalize_weights(lg_engine* e) {
 int lg_engine_reserve(lg_engine* e, int32_t max_batch, int32_t max_n0, int32_t max_n1) {
     if (!e || max_batch < 1 || max_n0 < 0 || max_n1 < 0) return fail(LG_ERR_INVALID, "bad argument");
     return ensure_workspace(e, max_batch, max_n0, max_n1);
+}
+
+int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
+    if (!e || !key) return fail(LG_ERR_INVALID, "null argument");
+    if (std::strcmp(key, "fused_tail") == 0) { e->fused_tail = value != 0; return LG_OK; }
+    return fail(LG_ERR_INVALID, std::string("unknown option '") + key + "'");
 }
 
 int lg_engine_debug_stop_after(lg_engine* e, int32_t step) { if (!e) return fail(LG_ERR_INVALID, "null engine"); e->debug_stop = step; return LG_OK; }
@@ -511,6 +580,20 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 TRY(prof_end(e, s));
             }
             STEP_DONE();
+            if (e->fused_tail) {   // out_proj + ffn.0 + LayerNorm + GELU + ffn.3 + residual in one kernel (lg_tail.hip)
+                TailArgs ta{};
+                ta.rs = rs_act; ta.X = e->X; ta.CTX = e->CTX;
+                ta.Wcat = (blk ? e->w_ctail_cat : e->w_stail_cat) + (size_t)i * e->tail_cat_layer_bytes;
+                ta.bcat = (blk ? e->b_ccat : e->b_scat) + (size_t)i * 512;
+                ta.gamma = (blk ? e->ln_c_g : e->ln_s_g) + (size_t)i * 512; ta.beta = (blk ? e->ln_c_b : e->ln_s_b) + (size_t)i * 512;
+                ta.W2 = (blk ? e->w_ctail_2 : e->w_stail_2) + (size_t)i * e->tail_2_layer_bytes;
+                ta.b2 = (blk ? e->b_cf2 : e->b_sf2) + (size_t)i * D;
+                TRY(prof_begin(e, PC_TAIL, s));
+                HIPCHK(launch_tail(prec, ta, s));
+                TRY(prof_end(e, s));
+                STEP_DONE(); STEP_DONE(); STEP_DONE(); STEP_DONE();
+                continue;
+            }
             {
                 GemmArgs g = gemm(EPI_STORE, rs_act, e->CTX, D, nullptr, 0, D, D, woff(blk ? e->w_cout : e->w_sout, (size_t)i * D * D),
                                   (blk ? e->b_cout : e->b_sout) + (size_t)i * D, D, e->MSG, D, 1.f);

@@ -41,6 +41,19 @@ struct SimArgs {
 };
 hipError_t launch_sim(int prec, const SimArgs& a, hipStream_t s);
 
+// ---------------------------------------------------------------- fused block tail (lg_tail.hip)
+// x <- x + ffn(cat[x, out_proj(ctx)]) with out_proj folded into ffn.0 on the host (see lg_tail.hip).
+// Weights are packed in MFMA-fragment order: plane p (hi, lo) at element offset p*rows*512, and within a
+// plane element ((nt*NKC + kc)*64 + lane)*EPC + j = W[nt*16 + (lane&15)][kc*4*EPC + (lane>>4)*EPC + j].
+struct TailArgs {
+    RowSpace rs;
+    float* X; const float* CTX;
+    const void* Wcat; const float* bcat;     // [512][512] fragment-packed, [512]
+    const float* gamma; const float* beta;   // LayerNorm(512)
+    const void* W2; const float* b2;         // [256][512] fragment-packed, [256]
+};
+hipError_t launch_tail(int prec, const TailArgs& a, hipStream_t s);
+
 // ---------------------------------------------------------------- attention (lg_attention.hip)
 struct AttnArgs {
     RowSpace rs;

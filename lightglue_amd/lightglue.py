@@ -352,6 +352,11 @@ class LightGlue(nn.Module):
             "prune1": prune1,
         }
 
+    def set_option(self, key: str, value: int, device="cuda"):
+        """Engine options (include/lightglue_amd.h lg_engine_set_option), e.g. ("fused_tail", 0)."""
+        h = self._get_engine(torch.device(device))
+        _cabi.check(_cabi.load().lg_engine_set_option(h, key.encode(), int(value)))
+
     # ------------------------------------------------------------------ per-kernel timing (HIP events)
     def profile(self, enable: bool, device="cuda"):
         h = self._get_engine(torch.device(device))

@@ -51,7 +51,7 @@ def err(a, b):
     return float(d), float(d / (rms + 1e-30))
 
 
-def stage_errors(sd, data, precision, conf_kw, layer=0):
+def stage_errors(sd, data, precision, conf_kw, layer=0, fused=False):
     """Run the pipeline up to every step of `layer` and compare the step's output buffer with the
     oracle.  Returns {stage name: (max abs err, err / rms)}."""
     B, n0 = data["image0"]["keypoints"].shape[:2]
@@ -66,6 +66,7 @@ def stage_errors(sd, data, precision, conf_kw, layer=0):
                        g(d0, "image_size"), g(d1, "image_size"), g(d0, "scales"), g(d0, "oris"), g(d1, "scales"), g(d1, "oris"), trace=tr)
         traces.append(tr)
     model = make_model(sd, precision, **conf_kw)
+    model.set_option("fused_tail", int(fused))   # unfused: every intermediate buffer of the chain exists
     tdata = to_torch(data)
     res = {}
     L = layer
@@ -109,12 +110,13 @@ def stage_errors(sd, data, precision, conf_kw, layer=0):
     cmp_heads("self.v^T", read_attn_buf(model, "VT"), True, lambda t, im: t[f"l{L}_self{im}_v"])
     rows = run_to(base + 1)
     cmp_rows("self.attn_ctx", model.debug_read("CTX"), 256, lambda t, im: t[f"l{L}_self{im}_ctx"])
-    rows = run_to(base + 2)
-    cmp_rows("self.out_proj", model.debug_read("MSG"), 256, lambda t, im: t[f"l{L}_self{im}_msg"])
-    rows = run_to(base + 3)
-    cmp_rows("self.ffn0", model.debug_read("H1"), 512, lambda t, im: t[f"l{L}_self{im}_h1"])
-    rows = run_to(base + 4)
-    cmp_rows("self.ln_gelu", model.debug_read("G"), 512, lambda t, im: t[f"l{L}_self{im}_g"])
+    if not fused:
+        rows = run_to(base + 2)
+        cmp_rows("self.out_proj", model.debug_read("MSG"), 256, lambda t, im: t[f"l{L}_self{im}_msg"])
+        rows = run_to(base + 3)
+        cmp_rows("self.ffn0", model.debug_read("H1"), 512, lambda t, im: t[f"l{L}_self{im}_h1"])
+        rows = run_to(base + 4)
+        cmp_rows("self.ln_gelu", model.debug_read("G"), 512, lambda t, im: t[f"l{L}_self{im}_g"])
     rows = run_to(base + 5)
     cmp_rows("self.x_out", model.debug_read("X"), 256, lambda t, im: t[f"l{L}_xs{im}"])
     rows = run_to(base + 6)
@@ -122,12 +124,13 @@ def stage_errors(sd, data, precision, conf_kw, layer=0):
     cmp_heads("cross.v^T", read_attn_buf(model, "VT"), True, lambda t, im: t[f"l{L}_cross_v{im}"])
     rows = run_to(base + 7)
     cmp_rows("cross.attn_ctx", model.debug_read("CTX"), 256, lambda t, im: t[f"l{L}_cross_ctx{im}"])
-    rows = run_to(base + 8)
-    cmp_rows("cross.to_out", model.debug_read("MSG"), 256, lambda t, im: t[f"l{L}_cross_msg{im}"])
-    rows = run_to(base + 9)
-    cmp_rows("cross.ffn0", model.debug_read("H1"), 512, lambda t, im: t[f"l{L}_cross_i{im}_h1"])
-    rows = run_to(base + 10)
-    cmp_rows("cross.ln_gelu", model.debug_read("G"), 512, lambda t, im: t[f"l{L}_cross_i{im}_g"])
+    if not fused:
+        rows = run_to(base + 8)
+        cmp_rows("cross.to_out", model.debug_read("MSG"), 256, lambda t, im: t[f"l{L}_cross_msg{im}"])
+        rows = run_to(base + 9)
+        cmp_rows("cross.ffn0", model.debug_read("H1"), 512, lambda t, im: t[f"l{L}_cross_i{im}_h1"])
+        rows = run_to(base + 10)
+        cmp_rows("cross.ln_gelu", model.debug_read("G"), 512, lambda t, im: t[f"l{L}_cross_i{im}_g"])
     rows = run_to(base + 11)
     cmp_rows("cross.x_out", model.debug_read("X"), 256, lambda t, im: t[f"desc{im}_l{L}"])
     model.debug_stop_after(-1)

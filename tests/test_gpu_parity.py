@@ -76,15 +76,29 @@ def test_default_precision_parity(name):
     np.testing.assert_array_equal(out["prune0"].cpu().numpy().astype(np.float32), gold["prune0"])
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16x3", 5e-4), ("fp16", 2e-2), ("bf16", 1e-1)])
-def test_pipeline_stages_layer0(precision, tol):
-    """Every kernel of layer 0 against the oracle's intermediate tensors (err relative to rms)."""
+def test_pipeline_stages_layer0(precision, tol, fused):
+    """Every kernel of layer 0 against the oracle's intermediate tensors (err relative to rms); once with
+    the unfused per-op kernels (every intermediate is observable) and once with the fused block tail."""
     require_gpu()
     sd = synth.make_state_dict(0, recipe="A")
     data = synth.make_batch(7, 2, 200, 160)
-    res = gpu_util.stage_errors(sd, data, precision, dict(depth_confidence=-1, width_confidence=-1))
+    res = gpu_util.stage_errors(sd, data, precision, dict(depth_confidence=-1, width_confidence=-1), fused=fused)
     bad = {k: v for k, v in res.items() if not (v[1] <= (tol if not k.startswith(("self.q", "self.k", "self.v", "cross.qk", "cross.v")) else max(tol, {"fp32": 2e-5, "bf16x3": 3e-3, "fp16": 5e-3, "bf16": 5e-2}[precision])))}
     assert not bad, bad
+
+
+def test_unfused_path_matches_golden():
+    """The per-op kernels (fused_tail = 0) stay a valid product configuration."""
+    require_gpu()
+    meta, gold = load_golden("nonadaptive_512")
+    sd, data = make_golden.case_inputs(meta["case"])
+    model = gpu_util.make_model(sd, "fp32", **meta["case"]["conf"])
+    model.set_option("fused_tail", 0)
+    out = model(gpu_util.to_torch(data))
+    np.testing.assert_array_equal(out["matches0"].cpu().numpy(), gold["matches0"])
+    np.testing.assert_allclose(out["matching_scores0"].cpu().numpy(), gold["matching_scores0"], atol=2e-4, rtol=0)
 
 
 def test_plain_bf16_mismatch_rate_is_reported_not_hidden():

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
         __syncthreads();
         store_tile(kv0);
         __syncthreads();
-        if (tile + 1 < ntiles) load_tile(kv0 + ABK);
+        load_tile(tile + 1 < ntiles ? kv0 + ABK : kv0);   // clamped, not branched (keeps hipcc's vmcnt counting exact)
+        __builtin_amdgcn_sched_barrier(0);                // and pinned ahead of the MFMAs
 
         // ---- S^T = K Q^T  (4 key tiles x 2 query tiles)
         f32x4 s[4][2];

@@ -128,6 +128,21 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// ---- DPP cross-lane helpers (VALU data path, no LDS traffic unlike ds_bpermute-based __shfl)
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor1(float v) { return dpp_mov<0xB1>(v); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float dpp_xor2(float v) { return dpp_mov<0x4E>(v); }   // quad_perm [2,3,0,1]
+// sum over the 16 lanes of a DPP row (lanes sharing lane >> 4); every lane of the row gets the total
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_xor1(v);
+    v += dpp_xor2(v);
+    v += dpp_mov<0x141>(v);   // row_half_mirror: lane i <- lane 7 - i  (the other quad of the 8-lane half)
+    v += dpp_mov<0x140>(v);   // row_mirror:      lane i <- lane 15 - i (the other half of the row)
+    return v;
+}
+
 // ---- wave helpers (wave = 64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -92,6 +92,7 @@ struct lg_engine {
     float *b_scat = nullptr, *b_ccat = nullptr;
     size_t tail_cat_layer_bytes = 0, tail_2_layer_bytes = 0;
     int fused_tail = 1;
+    int tail_timing = 0; long long* TAILDBG = nullptr;
     // ---- workspace
     void* ws = nullptr; size_t ws_bytes = 0;
     int capB = 0, cap0 = 0, cap1 = 0;      // reserved
@@ -202,6 +203,7 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
         for (int i = 0; i < 3; ++i) add(R * 256 * as);          // Q K VT
         add(R * 4); add(R * 4);                                 // IND DST
         for (int i = 0; i < 4; ++i) add((size_t)nB * 2 * 4);    // LEN LEN_OLD ACTIVE FINAL_LAYER
+        add(R / 64 * 64 * 8);                                   // TAILDBG
         total += 4096;
         HIPCHK(hipMalloc(&e->ws, total));
         e->ws_bytes = total;
@@ -228,6 +230,7 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
     e->IND = (int*)take("IND", R * 4); e->DST = (int*)take("DST", R * 4);
     e->LEN = (int*)take("LEN", (size_t)B * 2 * 4); e->LEN_OLD = (int*)take("LEN_OLD", (size_t)B * 2 * 4);
     e->ACTIVE = (int*)take("ACTIVE", (size_t)B * 4); e->FINAL_LAYER = (int*)take("FINAL_LAYER", (size_t)B * 4);
+    e->TAILDBG = (long long*)take("TAILDBG", R / 64 * 64 * 8);
     if (ar.used > e->ws_bytes) return fail(LG_ERR_STATE, "workspace carve overflow");
     return LG_OK;
 }
@@ -470,6 +473,7 @@ int lg_engine_reserve(lg_engine* e, int32_t max_batch, int32_t max_n0, int32_t m
 int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
     if (!e || !key) return fail(LG_ERR_INVALID, "null argument");
     if (std::strcmp(key, "fused_tail") == 0) { e->fused_tail = value != 0; return LG_OK; }
+    if (std::strcmp(key, "tail_timing") == 0) { e->tail_timing = value != 0; return LG_OK; }
     return fail(LG_ERR_INVALID, std::string("unknown option '") + key + "'");
 }
 
@@ -588,6 +592,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 ta.gamma = (blk ? e->ln_c_g : e->ln_s_g) + (size_t)i * 512; ta.beta = (blk ? e->ln_c_b : e->ln_s_b) + (size_t)i * 512;
                 ta.W2 = (blk ? e->w_ctail_2 : e->w_stail_2) + (size_t)i * e->tail_2_layer_bytes;
                 ta.b2 = (blk ? e->b_cf2 : e->b_sf2) + (size_t)i * D;
+                ta.dbg = e->tail_timing ? e->TAILDBG : nullptr;
                 TRY(prof_begin(e, PC_TAIL, s));
                 HIPCHK(launch_tail(prec, ta, s));
                 TRY(prof_end(e, s));

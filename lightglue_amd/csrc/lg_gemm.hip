@@ -144,7 +144,9 @@ __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[4][4], const float* A
         ra.store(smA, tid);
         if constexpr (BF32) rbf.store(smB, tid); else rbp.store(smB, tid);
         __syncthreads();
-        if (k0 + KE < K) load_stage(k0 + KE);  // in flight during the MFMAs below
+        load_stage(k0 + KE < K ? k0 + KE : k0);  // in flight during the MFMAs below (clamped, never branched:
+                                                 // a conditional load makes hipcc wait vmcnt(0) at the join)
+        __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of the MFMAs (hipcc would sink it)
         compute_stage<PREC>(acc, smA, smB, wm, wn, lane);
     }
 }

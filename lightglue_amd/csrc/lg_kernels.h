@@ -51,6 +51,7 @@ struct TailArgs {
     const void* Wcat; const float* bcat;     // [512][512] fragment-packed, [512]
     const float* gamma; const float* beta;   // LayerNorm(512)
     const void* W2; const float* b2;         // [256][512] fragment-packed, [256]
+    long long* dbg;                          // profiling tap: [blocks][8 waves][8] shader-clock stamps, or nullptr
 };
 hipError_t launch_tail(int prec, const TailArgs& a, hipStream_t s);
 

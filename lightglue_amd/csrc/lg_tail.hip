@@ -15,9 +15,15 @@
 // they are pre-packed on the host in MFMA-fragment order and each B fragment is one fully coalesced
 // 1 KB wave load straight from L2 into registers (weights are ~2.3 MB per precision plane set and stay
 // L2-resident).
-//   phase A  h = [x ; ctx] Wcat^T + bcat      K = 512 streamed HBM -> regs -> (convert) -> LDS, double buffered
-//   LN/GELU  two-pass row statistics across the 8 waves (LDS), exact erf GELU, all in registers
-//   phase B  out = g W2^T + b2 (+ x)          g is written once to LDS in A-operand order (128 KB for split bf16)
+//   phase A  h = [x ; ctx] Wcat^T + bcat.  The whole 64 x 512 activation tile lives in LDS (128 KB as split
+//            bf16): the x half is loaded/converted first, the ctx half is fetched while the x half is being
+//            multiplied -> two barriers for the whole phase, weight fragments prefetched from L2 on a ring.
+//            Wave w owns the n-tiles {w, w+8, w+16, w+24} (16 hidden units each).
+//   LN       two-pass row statistics across the 8 waves (LDS scratch), in registers
+//   phase B  out = g W2^T + b2 in 4 steps: step j multiplies K-stages 2j, 2j+1 of g (128 hidden units), then the
+//            wave applies GELU to its next n-tile and writes it to LDS in A-operand order (one barrier per step).
+//            (Running the two halves of the workgroup in opposite MFMA/GELU order to overlap the pipes was
+//            measured and lost 8k cycles per workgroup; see DESIGN.md.)
 //   epilogue out tile staged through LDS, residual add and store as full 1 KB rows
 #include "lg_kernels.h"
 
@@ -41,6 +47,32 @@ template <int PREC> struct TL {
     static constexpr int RED_BYTES = 8 * TBM * 4;
     static constexpr int TOTAL = G_BYTES + RED_BYTES;
 };
+
+// GELU(u) = 0.5 u (1 + erf(u / sqrt 2)) with a branch-free erf:  erf(|x|) = 1 - exp(-x^2) * sum_{k=1..8} c_k t^k,
+// t = 1 / (1 + 0.3275911 |x|)  (Abramowitz-Stegun 7.1.26 form, coefficients re-fitted to degree 8 here:
+// max |erf error| 4.2e-7, max |GELU error| 9.7e-8 over [-10, 10] in fp32 — fp32 round-off class).  The ocml
+// erff costs ~10x more instructions (two divergent ranges) and was a third of this kernel's time.
+// Two values at a time so that the polynomial runs on v_pk_fma_f32 / v_pk_mul_f32.
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 u) {
+    const f32x2 x = u * 0.70710678118654752440f;
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2 den = ax * 0.3275911f + 1.0f;
+    const f32x2 tt = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    f32x2 p = tt * -0.0779742014f + 0.151737503f;
+    p = p * tt + 0.39572154f;
+    p = p * tt + -0.574341196f;
+    p = p * tt + 0.810336914f;
+    p = p * tt + -0.151473053f;
+    p = p * tt + 0.270560832f;
+    p = p * tt + 0.175431661f;
+    p = p * tt;
+    const f32x2 ee = ax * ax * -1.44269504088896340736f;
+    const f32x2 e = {__builtin_amdgcn_exp2f(ee[0]), __builtin_amdgcn_exp2f(ee[1])};
+    const f32x2 er = 1.0f - p * e;                       // erf(|x|)
+    const f32x2 half_u = u * 0.5f;
+    const f32x2 sgn = {copysignf(er[0], x[0]), copysignf(er[1], x[1])};
+    return half_u + half_u * sgn;
+}
 
 template <int PREC>
 __device__ __forceinline__ void tail_mma(f32x4& acc, const u32x4* a, const u32x4* b) {
@@ -68,6 +100,11 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     if (t.r0 >= a.rs.len[t.seg]) return;
     if (a.rs.active && !a.rs.active[t.pair]) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
+    // optional per-phase shader-clock stamps (profiling tap; a.dbg == nullptr in production)
+    auto stamp = [&](int slot) {
+        if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8 + slot] = clock64();
+    };
+    stamp(0);
 
     // ------------------------------------------------------------------ phase A
     f32x4 acc[4][4];
@@ -76,28 +113,6 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int srow = tid >> 3, sslot = tid & 7;      // this thread's staged chunk: 64 rows x 8 slots
-    f32x4 stg[NV];
-    auto load_stage = [&](int s) {
-        const int k0 = s * KE;
-        const float* src = (k0 < 256 ? a.X : a.CTX) + (long long)(t.grow0 + srow) * 256 + (k0 & 255) + sslot * EPC;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) stg[j] = *reinterpret_cast<const f32x4*>(src + 4 * j);
-    };
-    auto store_stage = [&](int s) {
-        char* buf = smem + (s & 1) * NPART * TILE;
-        const int off = lds_off<128>(srow, sslot);
-        if constexpr (PREC == PREC_F32) {
-            *reinterpret_cast<f32x4*>(buf + off) = stg[0];
-        } else if constexpr (PREC == PREC_BF16X3) {
-            u32x4 hi, lo;
-            split8_bf16(stg[0], stg[1], hi, lo);
-            *reinterpret_cast<u32x4*>(buf + off) = hi;
-            *reinterpret_cast<u32x4*>(buf + TILE + off) = lo;
-        } else {
-            *reinterpret_cast<u32x4*>(buf + off) = pack8<Tag>(stg[0], stg[1]);
-        }
-    };
     // weight fragment: plane p, n-tile nt, k-chunk kc -> 64 lanes x 16 B contiguous
     auto wfrag = [&](const void* base, int p, long long plane_elems, int nt, int kc) -> u32x4 {
         const char* ptr = static_cast<const char*>(base) + (p ? plane_elems * (long long)sizeof(typename Tag::elem) : 0);
@@ -106,43 +121,93 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     const void* Wc = a.Wcat;
     const void* W2 = a.W2;
 
-    u32x4 bf[2][4][NPART];   // double-buffered B fragments of one k-chunk: 4 n-tiles x planes
-    auto load_b_A = [&](int buf, int kc) {
+    // ---- activation tile -> LDS.  Half hf (0: x, 1: ctx) = 64 rows x 256 floats = STAGES/2 K-stage tiles.
+    // Thread -> (row = tid >> 3, 16-byte-chunk slot = tid & 7) of every stage tile of the half.
+    constexpr int HS = STAGES / 2;                    // stage tiles per half (4, or 8 for f32)
+    const int srow = tid >> 3, sslot = tid & 7;
+    f32x4 hreg[HS][NV];
+    auto load_half = [&](int hf) {
+        const float* src = (hf ? a.CTX : a.X) + (long long)(t.grow0 + srow) * 256 + sslot * EPC;
+#pragma unroll
+        for (int st = 0; st < HS; ++st)
+#pragma unroll
+            for (int j = 0; j < NV; ++j) hreg[st][j] = *reinterpret_cast<const f32x4*>(src + st * KE + 4 * j);
+    };
+    auto store_half = [&](int hf) {
+        const int off = lds_off<128>(srow, sslot);
+#pragma unroll
+        for (int st = 0; st < HS; ++st) {
+            char* tile = smem + (hf * HS + st) * TILE;   // planes: p * G_PLANE
+            if constexpr (PREC == PREC_F32) {
+                *reinterpret_cast<f32x4*>(tile + off) = hreg[st][0];
+            } else if constexpr (PREC == PREC_BF16X3) {
+                u32x4 hi, lo;
+                split8_bf16(hreg[st][0], hreg[st][1], hi, lo);
+                *reinterpret_cast<u32x4*>(tile + off) = hi;
+                *reinterpret_cast<u32x4*>(tile + G_PLANE + off) = lo;
+            } else {
+                *reinterpret_cast<u32x4*>(tile + off) = pack8<Tag>(hreg[st][0], hreg[st][1]);
+            }
+        }
+    };
+    // NOTE no branch around prefetches anywhere in this kernel: hipcc counts s_waitcnt conservatively at a join,
+    // so a conditional load forces vmcnt(0) right after it (guide §5 trap (c)); past-the-end prefetches are
+    // clamped instead.  sched_barrier(0) pins the software pipeline (hipcc otherwise sinks a prefetch next to
+    // its use to save registers, i.e. un-pipelines the loop).
+    constexpr int NBUF = NPART == 2 ? 2 : 4;
+    u32x4 bf[NBUF][4][NPART];   // ring of B fragments: this wave's 4 n-tiles x planes per k-chunk
+    auto load_b_A = [&](u32x4 (&dst)[4][NPART], int kc) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int p = 0; p < NPART; ++p) bf[buf][nt][p] = wfrag(Wc, p, 512LL * 512, w * 4 + nt, kc);
+            for (int p = 0; p < NPART; ++p) dst[nt][p] = wfrag(Wc, p, 512LL * 512, w + 8 * nt, kc);
     };
-    load_stage(0);
-    load_b_A(0, 0);
+    auto chunk_A = [&](int kc, const u32x4 (&b)[4][NPART]) {   // one k-chunk of MFMAs against the LDS-resident tile
+        const char* tile = smem + (kc >> 1) * TILE;
+        u32x4 af[4][NPART];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int p = 0; p < NPART; ++p)
+                af[mt][p] = *reinterpret_cast<const u32x4*>(tile + p * G_PLANE + lds_off<128>(mt * 16 + lr, (kc & 1) * 4 + g));
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) tail_mma<PREC>(acc[mt][nt], af[mt], b[nt]);
+    };
+    load_half(0);
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) load_b_A(bf[i], i);
+    store_half(0);
+    __syncthreads();
+    load_half(1);                       // ctx rows stream in while the x half is multiplied
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int HC = NKC / 2;         // k-chunks per half
 #pragma unroll 1
-    for (int s = 0; s < STAGES; ++s) {
-        store_stage(s);
-        __syncthreads();
-        if (s + 1 < STAGES) load_stage(s + 1);
-        const char* buf = smem + (s & 1) * NPART * TILE;
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll 1
+        for (int c0 = 0; c0 < HC; c0 += NBUF) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int kc = 2 * s + ks;
-            if (kc + 1 < NKC) load_b_A((ks + 1) & 1, kc + 1);   // next chunk's weights in flight
-            u32x4 af[4][NPART];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int p = 0; p < NPART; ++p)
-                    af[mt][p] = *reinterpret_cast<const u32x4*>(buf + p * TILE + lds_off<128>(mt * 16 + lr, ks * 4 + g));
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) tail_mma<PREC>(acc[mt][nt], af[mt], bf[ks & 1][nt]);
+            for (int i = 0; i < NBUF; ++i) {
+                const int kc = hf * HC + c0 + i;
+                load_b_A(bf[(i + NBUF - 1) % NBUF], kc + NBUF - 1 < NKC ? kc + NBUF - 1 : NKC - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                chunk_A(kc, bf[i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (hf == 0) {
+            store_half(1);
+            __syncthreads();
         }
     }
+    stamp(1);
     // ------------------------------------------------------------------ bias + LayerNorm(512) + GELU
     {
         float bias[4], gam[4], bet[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const int col = w * 64 + nt * 16 + lr;
+            const int col = (w + 8 * nt) * 16 + lr;
             bias[nt] = a.bcat[col]; gam[nt] = a.gamma[col]; bet[nt] = a.beta[col];
         }
         float part[4][4];   // [mt][r] partial sums over this lane's 4 columns
@@ -160,9 +225,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = p[mt][r];
-                    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-                    p[mt][r] = v;
+                    p[mt][r] = row16_sum(p[mt][r]);
                 }
             __syncthreads();   // previous users of `red` (and, first time, of the staging buffers) are done
             if (lr == 0) {
@@ -173,14 +236,13 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             }
             __syncthreads();
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < 4; ++mt) {   // rows 4g..4g+3 of tile mt are contiguous: one 16-byte read per wave slot
+                f32x4 v = *reinterpret_cast<const f32x4*>(red + mt * 16 + g * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = 0.f;
+                for (int ww = 1; ww < 8; ++ww) v += *reinterpret_cast<const f32x4*>(red + ww * TBM + mt * 16 + g * 4);
 #pragma unroll
-                    for (int ww = 0; ww < 8; ++ww) v += red[ww * TBM + mt * 16 + g * 4 + r];
-                    p[mt][r] = v;
-                }
+                for (int r = 0; r < 4; ++r) p[mt][r] = v[r];
+            }
         };
         block_row_sum(part);
         float mean[4][4];
@@ -199,33 +261,32 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float rstd = 1.f / sqrtf(part[mt][r] * (1.f / 512.f) + 1e-5f);
+                const float rstd = __builtin_amdgcn_rsqf(part[mt][r] * (1.f / 512.f) + 1e-5f);   // v_rsq_f32, 1 ulp
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const float u = acc[mt][nt][r] * rstd * gam[nt] + bet[nt];
-                    acc[mt][nt][r] = 0.5f * u * (1.f + erff(u * 0.70710678118654752440f));
-                }
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt][r] = acc[mt][nt][r] * rstd * gam[nt] + bet[nt];   // pre-GELU
             }
     }
-    // ------------------------------------------------------------------ g -> LDS in A-operand order
-    // all waves passed the second barrier of the last block_row_sum, i.e. nobody reads the staging buffers
-    // any more, so the g tiles may overwrite them.
-    if constexpr (EPC == 8) {
-        char* tile0 = smem + w * TILE;   // this wave's 64 columns are exactly K-stage w of phase B
+    stamp(2);
+    // ------------------------------------------------------------------ GELU + g -> LDS (A-operand order) + phase B
+    // n-tile j of wave w = hidden units [(w + 8j)*16, +16) = K-stage 2j + (w >> 2), columns (w & 3)*16 + lr of it.
+    auto gelu_store = [&](int j) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+        for (int mt = 0; mt < 4; ++mt) {
+            f32x2 v01 = gelu_fast2(f32x2{acc[mt][j][0], acc[mt][j][1]});
+            f32x2 v23 = gelu_fast2(f32x2{acc[mt][j][2], acc[mt][j][3]});
+            const float gv[4] = {v01[0], v01[1], v23[0], v23[1]};
+            if constexpr (EPC == 8) {
+                char* tile0 = smem + (2 * j + (w >> 2)) * TILE;
 #pragma unroll
                 for (int rp = 0; rp < 4; rp += 2) {
                     // even lanes write row rp, odd lanes row rp+1; each writes the (even col, odd col) pair
                     const bool odd = lr & 1;
-                    const float mine = odd ? acc[mt][nt][rp + 1] : acc[mt][nt][rp];
-                    const float give = odd ? acc[mt][nt][rp] : acc[mt][nt][rp + 1];
-                    const float got = __shfl_xor(give, 1, 64);
+                    const float mine = odd ? gv[rp + 1] : gv[rp];
+                    const float give = odd ? gv[rp] : gv[rp + 1];
+                    const float got = dpp_xor1(give);
                     const float c0 = odd ? got : mine, c1 = odd ? mine : got;   // values at (even col, odd col)
                     const int row = mt * 16 + g * 4 + rp + (odd ? 1 : 0);
-                    const int col = nt * 16 + (lr & ~1);
+                    const int col = (w & 3) * 16 + (lr & ~1);
                     const int off = lds_off<128>(row, col >> 3) + (col & 7) * 2;
                     if constexpr (PREC == PREC_BF16X3) {
                         const float h0 = bf16_round(c0), h1 = bf16_round(c1);
@@ -235,49 +296,66 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
                         *reinterpret_cast<uint32_t*>(tile0 + off) = pack2<Tag>(c0, c1);
                     }
                 }
-    } else {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int c = nt * 16 + lr, row = mt * 16 + g * 4 + r;
-                    char* tile = smem + (2 * w + (c >> 5)) * TILE;
-                    *reinterpret_cast<float*>(tile + lds_off<128>(row, (c & 31) >> 2) + (c & 3) * 4) = acc[mt][nt][r];
+                    const int hcol = (w + 8 * j) * 16 + lr, row = mt * 16 + g * 4 + r;   // f32: K-stage = 32 hidden units
+                    char* tile = smem + (hcol >> 5) * TILE;
+                    *reinterpret_cast<float*>(tile + lds_off<128>(row, (hcol & 31) >> 2) + (hcol & 3) * 4) = gv[r];
                 }
-    }
-    __syncthreads();
-    // ------------------------------------------------------------------ phase B: out[64 x 256], wave w -> columns [32w, 32w+32)
+            }
+        }
+    };
+    // all waves passed the barriers of the last block_row_sum => the activation tile is dead, g may overwrite it
     f32x4 acc2[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc2[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    u32x4 b2f[2][2][NPART];
-    auto load_b_B = [&](int buf, int kc) {
+    u32x4 b2f[4][2][NPART];   // ring, 3 k-chunks ahead
+    auto load_b_B = [&](u32x4 (&dst)[2][NPART], int kc) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int p = 0; p < NPART; ++p) b2f[buf][nt][p] = wfrag(W2, p, 256LL * 512, w * 2 + nt, kc);
+            for (int p = 0; p < NPART; ++p) dst[nt][p] = wfrag(W2, p, 256LL * 512, w * 2 + nt, kc);
     };
-    load_b_B(0, 0);
-#pragma unroll 1
-    for (int st = 0; st < STAGES; ++st) {
-        const char* tile = smem + st * TILE;
+    auto chunk_B = [&](int kc, const u32x4 (&b)[2][NPART]) {
+        const char* tile = smem + (kc >> 1) * TILE;
+        u32x4 af[4][NPART];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {     // register double buffer indexed by the compile-time ks
-            const int kc = 2 * st + ks;
-            if (kc + 1 < NKC) load_b_B((ks + 1) & 1, kc + 1);
-            u32x4 af[4][NPART];
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int p = 0; p < NPART; ++p)
+                af[mt][p] = *reinterpret_cast<const u32x4*>(tile + p * G_PLANE + lds_off<128>(mt * 16 + lr, (kc & 1) * 4 + g));
 #pragma unroll
-                for (int p = 0; p < NPART; ++p)
-                    af[mt][p] = *reinterpret_cast<const u32x4*>(tile + p * G_PLANE + lds_off<128>(mt * 16 + lr, ks * 4 + g));
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int nt = 0; nt < 2; ++nt) tail_mma<PREC>(acc2[mt][nt], af[mt], b[nt]);
+    };
+    load_b_B(b2f[0], 0); load_b_B(b2f[1], 1); load_b_B(b2f[2], 2);
+    gelu_store(0);
+    __syncthreads();
+    stamp(3);
+    constexpr int CPS = NKC / 4;   // k-chunks per step (4 for 16-bit: K-stages 2j, 2j+1; 8 for f32)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) tail_mma<PREC>(acc2[mt][nt], af[mt], b2f[ks & 1][nt]);
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < CPS; ++i) {
+            const int kc = j * CPS + i;
+            load_b_B(b2f[(kc + 3) & 3], kc + 3 < NKC ? kc + 3 : NKC - 1);
+            chunk_B(kc, b2f[kc & 3]);
         }
+        if (j < 3) {
+            gelu_store(j + 1);
+            __syncthreads();
+        }
+    }
+    stamp(4);
+    // residual rows for the epilogue: issue the loads now so that they land during the output staging
+    const int qlen = a.rs.len[t.seg];
+    f32x4 xres[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = tid + TTHREADS * i, row = c >> 6, c4 = c & 63;
+        xres[i] = *reinterpret_cast<const f32x4*>(a.X + (long long)(t.grow0 + row) * 256 + c4 * 4);
     }
     __syncthreads();   // g tiles are dead; reuse the region as a [64][256+4] fp32 output tile
     {
@@ -293,18 +371,16 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
                 for (int r = 0; r < 4; ++r) ot[(mt * 16 + g * 4 + r) * OLD + col] = acc2[mt][nt][r] + b2;
         }
         __syncthreads();
-        const int qlen = a.rs.len[t.seg];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {     // 64 rows x 64 float4 = 4096 chunks, 8 per thread; a wave covers one full row
             const int c = tid + TTHREADS * i, row = c >> 6, c4 = c & 63;
             if (t.r0 + row < qlen) {
-                float* xp = a.X + (long long)(t.grow0 + row) * 256 + c4 * 4;
-                const f32x4 x = *reinterpret_cast<const f32x4*>(xp);
                 const f32x4 d = *reinterpret_cast<const f32x4*>(ot + row * OLD + c4 * 4);
-                *reinterpret_cast<f32x4*>(xp) = x + d;
+                *reinterpret_cast<f32x4*>(a.X + (long long)(t.grow0 + row) * 256 + c4 * 4) = xres[i] + d;
             }
         }
     }
+    stamp(5);
 }
 
 template <int PREC> static hipError_t launch_tail_prec(const TailArgs& a, hipStream_t s) {

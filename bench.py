@@ -132,6 +132,7 @@ def main():
     model.reserve(B, n, m, dev)
     if args.unfused:
         model.set_option("fused_tail", 0, dev)
+        model.set_option("fused_proj", 0, dev)
     sharded = PairShardedMatcher(model) if world > 1 else None
 
     def step():

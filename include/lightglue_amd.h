@@ -96,7 +96,8 @@ int lg_engine_reserve(lg_engine* e, int32_t max_batch, int32_t max_n0, int32_t m
 int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream);
 
 /* Engine options.  "fused_tail" (default 1): run out_proj + ffn + LayerNorm + GELU + residual as one kernel
- * (lg_tail.hip); 0 selects the unfused per-layer kernels (kept for stage-by-stage parity tests). */
+ * (lg_tail.hip); "fused_proj" (default 1): the full-width q/k/v projection kernel (lg_proj.hip).  0 selects the
+ * generic per-op GEMM kernels (kept for stage-by-stage parity tests). */
 int lg_engine_set_option(lg_engine* e, const char* key, int32_t value);
 
 /* ---- test / profiling taps (not used by the product path) ---- */

@@ -91,7 +91,9 @@ struct lg_engine {
     char *w_stail_cat = nullptr, *w_stail_2 = nullptr, *w_ctail_cat = nullptr, *w_ctail_2 = nullptr;
     float *b_scat = nullptr, *b_ccat = nullptr;
     size_t tail_cat_layer_bytes = 0, tail_2_layer_bytes = 0;
-    int fused_tail = 1;
+    char *w_sqkv_p = nullptr, *w_cqkv_p = nullptr;   // fragment-packed projection weights (lg_proj.hip)
+    size_t sqkv_layer_bytes = 0, cqkv_layer_bytes = 0;
+    int fused_tail = 1, fused_proj = 1;
     int tail_timing = 0; long long* TAILDBG = nullptr;
     // ---- workspace
     void* ws = nullptr; size_t ws_bytes = 0;
@@ -342,6 +344,8 @@ int lg_engine_finalize_weights(lg_engine* e) {
     const size_t planes = split ? 2 : 1;
     const size_t cat_layer = (size_t)512 * 512 * es * planes, w2_layer = (size_t)256 * 512 * es * planes;
     for (int i = 0; i < 2; ++i) { total = ((total + 255) & ~size_t(255)) + L * cat_layer; total = ((total + 255) & ~size_t(255)) + L * w2_layer; }
+    const size_t sqkv_layer = (size_t)768 * 256 * es * planes, cqkv_layer = (size_t)512 * 256 * es * planes;
+    total = ((total + 255) & ~size_t(255)) + L * sqkv_layer; total = ((total + 255) & ~size_t(255)) + L * cqkv_layer;
     addf((size_t)L * 512); addf((size_t)L * 512);
     total += 4096;
     if (e->w_arena) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(e->w_arena)); e->w_arena = nullptr; }
@@ -362,6 +366,8 @@ int lg_engine_finalize_weights(lg_engine* e) {
     e->w_stail_cat = static_cast<char*>(ar.take(L * cat_layer)); e->w_stail_2 = static_cast<char*>(ar.take(L * w2_layer));
     e->w_ctail_cat = static_cast<char*>(ar.take(L * cat_layer)); e->w_ctail_2 = static_cast<char*>(ar.take(L * w2_layer));
     e->b_scat = takef((size_t)L * 512); e->b_ccat = takef((size_t)L * 512);
+    e->sqkv_layer_bytes = sqkv_layer; e->cqkv_layer_bytes = cqkv_layer;
+    e->w_sqkv_p = static_cast<char*>(ar.take(L * sqkv_layer)); e->w_cqkv_p = static_cast<char*>(ar.take(L * cqkv_layer));
 
     std::string err;
     auto up_f32 = [&](float* dst, const float* src, size_t n) -> int { HIPCHK(hipMemcpy(dst, src, n * 4, hipMemcpyHostToDevice)); return LG_OK; };
@@ -387,6 +393,7 @@ int lg_engine_finalize_weights(lg_engine* e) {
                 pb[dst] = b->data[src];
             }
             TRY(upload_packed(prec, pw.data(), pw.size(), e->w_sqkv, (size_t)i * 768 * D));
+            TRY(upload_fragment_packed(prec, std::vector<double>(pw.begin(), pw.end()), 768, D, e->w_sqkv_p + (size_t)i * sqkv_layer));
             TRY(up_f32(e->b_sqkv + (size_t)i * 768, pb.data(), 768));
         }
         {
@@ -440,6 +447,7 @@ int lg_engine_finalize_weights(lg_engine* e) {
             std::memcpy(pw.data() + (size_t)D * D, wv->data.data(), (size_t)D * D * 4);
             std::memcpy(pb.data(), bq->data.data(), D * 4); std::memcpy(pb.data() + D, bv->data.data(), D * 4);
             TRY(upload_packed(prec, pw.data(), pw.size(), e->w_cqkv, (size_t)i * 512 * D));
+            TRY(upload_fragment_packed(prec, std::vector<double>(pw.begin(), pw.end()), 512, D, e->w_cqkv_p + (size_t)i * cqkv_layer));
             TRY(up_f32(e->b_cqkv + (size_t)i * 512, pb.data(), 512));
             TRY(upload_packed(prec, wo->data.data(), (size_t)D * D, e->w_cout, (size_t)i * D * D));
             TRY(up_f32(e->b_cout + (size_t)i * D, bo->data.data(), D));
@@ -473,6 +481,7 @@ int lg_engine_reserve(lg_engine* e, int32_t max_batch, int32_t max_n0, int32_t m
 int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
     if (!e || !key) return fail(LG_ERR_INVALID, "null argument");
     if (std::strcmp(key, "fused_tail") == 0) { e->fused_tail = value != 0; return LG_OK; }
+    if (std::strcmp(key, "fused_proj") == 0) { e->fused_proj = value != 0; return LG_OK; }
     if (std::strcmp(key, "tail_timing") == 0) { e->tail_timing = value != 0; return LG_OK; }
     return fail(LG_ERR_INVALID, std::string("unknown option '") + key + "'");
 }
@@ -566,6 +575,17 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
 
     for (int i = 0; i < L; ++i) {
         for (int blk = 0; blk < 2; ++blk) {  // 0 = SelfBlock (ref :159-172), 1 = CrossBlock (ref :201-230)
+            if (e->fused_proj) {
+                ProjArgs pj{};
+                pj.rs = rs_act; pj.X = e->X; pj.R = R; pj.q = e->Q; pj.k = e->K; pj.vt = e->VT;
+                pj.W = blk == 0 ? e->w_sqkv_p + (size_t)i * e->sqkv_layer_bytes : e->w_cqkv_p + (size_t)i * e->cqkv_layer_bytes;
+                pj.bias = blk == 0 ? e->b_sqkv + (size_t)i * 768 : e->b_cqkv + (size_t)i * 512;
+                pj.Nout = blk == 0 ? 768 : 512; pj.n_qk_groups = blk == 0 ? 2 : 1;
+                pj.cosb = blk == 0 ? e->COS : nullptr; pj.sinb = blk == 0 ? e->SIN : nullptr;
+                TRY(prof_begin(e, blk == 0 ? PC_GEMM_QKV_SELF : PC_GEMM_QKV_CROSS, s));
+                HIPCHK(launch_proj(prec, ap, pj, s));
+                TRY(prof_end(e, s));
+            } else
             {
                 GemmArgs g = blk == 0 ? gemm(EPI_QKV, rs_act, e->X, D, nullptr, 0, D, D, woff(e->w_sqkv, (size_t)i * 768 * D), e->b_sqkv + (size_t)i * 768, 768, nullptr, 0, 1.f)
                                       : gemm(EPI_QKV, rs_act, e->X, D, nullptr, 0, D, D, woff(e->w_cqkv, (size_t)i * 512 * D), e->b_cqkv + (size_t)i * 512, 512, nullptr, 0, 1.f);

@@ -55,6 +55,19 @@ struct TailArgs {
 };
 hipError_t launch_tail(int prec, const TailArgs& a, hipStream_t s);
 
+// ---------------------------------------------------------------- attention input projections (lg_proj.hip)
+// q/k/v (self, rotary on q,k) or qk/v (cross) from the residual stream; weights fragment-packed like TailArgs
+// ([Nout][256], columns ordered [group][head][64], hi plane then lo plane).
+struct ProjArgs {
+    RowSpace rs;
+    const float* X;
+    const void* W; const float* bias; int Nout;       // 768 (self) or 512 (cross)
+    void* q; void* k; void* vt;                      // q,k: [H][R][64]   vt: [H][64][R]
+    const float* cosb; const float* sinb;            // rotary tables [R][32] or nullptr
+    int n_qk_groups; int R;
+};
+hipError_t launch_proj(int prec, int attn_prec, const ProjArgs& a, hipStream_t s);
+
 // ---------------------------------------------------------------- attention (lg_attention.hip)
 struct AttnArgs {
     RowSpace rs;

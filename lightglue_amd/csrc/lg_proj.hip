@@ -1,0 +1,241 @@
+// lightglue_amd — attention input projections as one kernel per block:
+//   SelfBlock  (ref lightglue.py:165-169): qkv = Wqkv x + b, split per head, rotary on q and k
+//   CrossBlock (ref :204-209):             qk = to_qk x + b, v = to_v x + b   (same weights for both images)
+// Output layouts feed lg_attention.hip directly: q, k [head][row][64], v TRANSPOSED [head][64][row].
+//
+// Same structure as the fused tail (lg_tail.hip): workgroup = 64 keypoint rows x ALL output columns, 8 waves
+// split the columns; the 64 x 256 activation tile is read from HBM exactly once, converted to the operand
+// precision and kept in LDS (64 KB as split bf16); weight fragments come pre-packed in MFMA order straight
+// from L2 (one coalesced 1 KB wave load each).  Wave w owns the n-tiles {w + 8j}: the columns are produced in
+// two passes of NTP n-tiles per wave (keeps accumulators + weight ring under the register budget) and each
+// pass's 64 x (NTP*128) output tile is staged through LDS so that q/k rows leave as full 128-byte lines and
+// v^T as 64-row lines (a head's 64 rows are contiguous in both layouts -> 8 KB contiguous stores).
+#include "lg_kernels.h"
+
+namespace lg {
+
+constexpr int PBM = 64, PTHREADS = 512;
+
+template <int PREC> struct PJ;
+template <> struct PJ<PREC_F32> { typedef TagF32 Tag; static constexpr int NPART = 1; };
+template <> struct PJ<PREC_BF16> { typedef TagBF16 Tag; static constexpr int NPART = 1; };
+template <> struct PJ<PREC_F16> { typedef TagF16 Tag; static constexpr int NPART = 1; };
+template <> struct PJ<PREC_BF16X3> { typedef TagBF16 Tag; static constexpr int NPART = 2; };
+
+template <class T> __device__ __forceinline__ T pj_cvt(float x);
+template <> __device__ __forceinline__ float pj_cvt<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t pj_cvt<bf16_t>(float x) { return (bf16_t)x; }
+template <> __device__ __forceinline__ f16_t pj_cvt<f16_t>(float x) { return (f16_t)x; }
+
+// NTP = n-tiles per wave per pass, NPASS passes: self (768 columns) 3 x 2 — or 2 x 3 when the staged outputs are
+// fp32 and 3 x 2 would not fit LDS —, cross (512 columns) 2 x 2.
+template <int PREC, class TA, int NTP, int NPASS>
+__global__ __launch_bounds__(PTHREADS) void proj_kernel(ProjArgs a) {
+    typedef typename PJ<PREC>::Tag Tag;
+    constexpr int EPC = Tag::EPC, NPART = PJ<PREC>::NPART;
+    constexpr int KE = 8 * EPC;               // K elements per 128-byte stage row (64 or 32)
+    constexpr int STAGES = 256 / KE;          // 4 (16-bit) or 8 (f32)
+    constexpr int NKC = 2 * STAGES;           // 16-byte k-chunks per row
+    constexpr int NV = EPC / 4;
+    constexpr int TILE = PBM * 128;           // one plane of one stage
+    constexpr int A_PLANE = STAGES * TILE;    // 32 KB (16-bit) / 64 KB (f32)
+    constexpr int NHC = NTP * 2;              // 64-column head chunks per pass (6 or 4)
+    constexpr int LINE = 64 * (int)sizeof(TA) + 16;   // padded staging line (64 elements)
+    constexpr int HCB = 64 * LINE;            // staging bytes of one head chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* smA = smem;                         // [NPART][STAGES][64][128 B]
+    char* smO = smem + NPART * A_PLANE;       // [NHC][64 lines][LINE]
+
+    const TileLoc t = locate_tile(a.rs, blockIdx.x, PBM);
+    if (t.r0 >= a.rs.len[t.seg]) return;
+    if (a.rs.active && !a.rs.active[t.pair]) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
+    const long long R = a.R;
+
+    auto wfrag = [&](int p, int nt, int kc) -> u32x4 {
+        const char* ptr = static_cast<const char*>(a.W) + (p ? (long long)a.Nout * 256 * (long long)sizeof(typename Tag::elem) : 0);
+        return *reinterpret_cast<const u32x4*>(ptr + ((long long)(nt * NKC + kc) * 64 + lane) * 16);
+    };
+    // ---- activation tile: HBM -> registers -> operand precision -> LDS (once)
+    {
+        const int srow = tid >> 3, sslot = tid & 7;
+        const float* src = a.X + (long long)(t.grow0 + srow) * 256 + sslot * EPC;
+        f32x4 hreg[STAGES][NV];
+#pragma unroll
+        for (int st = 0; st < STAGES; ++st)
+#pragma unroll
+            for (int j = 0; j < NV; ++j) hreg[st][j] = *reinterpret_cast<const f32x4*>(src + st * KE + 4 * j);
+        const int off = lds_off<128>(srow, sslot);
+#pragma unroll
+        for (int st = 0; st < STAGES; ++st) {
+            char* tile = smA + st * TILE;
+            if constexpr (PREC == PREC_F32) {
+                *reinterpret_cast<f32x4*>(tile + off) = hreg[st][0];
+            } else if constexpr (PREC == PREC_BF16X3) {
+                u32x4 hi, lo;
+                split8_bf16(hreg[st][0], hreg[st][1], hi, lo);
+                *reinterpret_cast<u32x4*>(tile + off) = hi;
+                *reinterpret_cast<u32x4*>(tile + A_PLANE + off) = lo;
+            } else {
+                *reinterpret_cast<u32x4*>(tile + off) = pack8<Tag>(hreg[st][0], hreg[st][1]);
+            }
+        }
+    }
+    constexpr int NBUF = NPART == 2 ? 2 : 4;
+    u32x4 bf[NBUF][NTP][NPART];
+    auto load_b = [&](u32x4 (&dst)[NTP][NPART], int pass, int kc) {
+#pragma unroll
+        for (int j = 0; j < NTP; ++j)
+#pragma unroll
+            for (int p = 0; p < NPART; ++p) dst[j][p] = wfrag(p, w + 8 * (pass * NTP + j), kc);
+    };
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) load_b(bf[i], 0, i);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int pass = 0; pass < NPASS; ++pass) {
+        f32x4 acc[4][NTP];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NTP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int c0 = 0; c0 < NKC; c0 += NBUF) {
+#pragma unroll
+            for (int i = 0; i < NBUF; ++i) {
+                const int kc = c0 + i;
+                // prefetch NBUF-1 chunks ahead; past the end of a pass, start on the next pass's first chunks
+                const int nk = kc + NBUF - 1;
+                const int npass = nk < NKC ? pass : (pass + 1 < NPASS ? pass + 1 : pass);
+                load_b(bf[(i + NBUF - 1) % NBUF], npass, nk < NKC ? nk : nk - NKC);
+                __builtin_amdgcn_sched_barrier(0);
+                const char* tile = smA + (kc >> 1) * TILE;
+                u32x4 af[4][NPART];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int p = 0; p < NPART; ++p)
+                        af[mt][p] = *reinterpret_cast<const u32x4*>(tile + p * A_PLANE + lds_off<128>(mt * 16 + lr, (kc & 1) * 4 + g));
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int j = 0; j < NTP; ++j) {
+                        if constexpr (NPART == 2) {
+                            mma_chunk<Tag>(acc[mt][j], af[mt][1], bf[i][j][0]);
+                            mma_chunk<Tag>(acc[mt][j], af[mt][0], bf[i][j][1]);
+                        }
+                        mma_chunk<Tag>(acc[mt][j], af[mt][0], bf[i][j][0]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- epilogue of the pass: bias, rotary, stage through LDS
+        if (pass > 0) __syncthreads();    // the previous pass's staged tile has been fully read
+#pragma unroll
+        for (int j = 0; j < NTP; ++j) {
+            const int nt = w + 8 * (pass * NTP + j);          // global n-tile
+            const int col0 = nt * 16;                         // global output column of lane lr == 0
+            const int group = col0 >> 8, d = (col0 & 63) + lr;
+            const int hcl = (col0 >> 6) - pass * NHC;         // head chunk within this pass
+            const float bv = a.bias[col0 + lr];
+            char* hc = smO + hcl * HCB;
+            if (group < a.n_qk_groups) {   // q / k (or qk): [row][64], written as (even, odd) column pairs
+                const bool rope = a.cosb != nullptr;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[mt][j][r] + bv;
+                        if (rope) {   // ref :58-65: pairs are adjacent columns = adjacent lanes
+                            const long long row = t.grow0 + mt * 16 + g * 4 + r;
+                            const float other = dpp_xor1(v[r]);
+                            const float c = a.cosb[row * 32 + (d >> 1)], s = a.sinb[row * 32 + (d >> 1)];
+                            v[r] = (d & 1) ? (v[r] * c + other * s) : (v[r] * c - other * s);
+                        }
+                    }
+                    if constexpr (sizeof(TA) == 2) {
+#pragma unroll
+                        for (int rp = 0; rp < 4; rp += 2) {
+                            const bool odd = lr & 1;
+                            const float mine = odd ? v[rp + 1] : v[rp];
+                            const float give = odd ? v[rp] : v[rp + 1];
+                            const float got = dpp_xor1(give);
+                            const float c0 = odd ? got : mine, c1 = odd ? mine : got;
+                            const int row = mt * 16 + g * 4 + rp + (odd ? 1 : 0);
+                            typedef TA ta2 __attribute__((ext_vector_type(2)));
+                            ta2 o = {pj_cvt<TA>(c0), pj_cvt<TA>(c1)};
+                            *reinterpret_cast<ta2*>(hc + row * LINE + (d & ~1) * 2) = o;
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(hc + (mt * 16 + g * 4 + r) * LINE + d * 4) = v[r];
+                    }
+                }
+            } else {                       // v: transposed [d][64 rows]; a lane holds 4 consecutive rows
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    typedef TA ta4 __attribute__((ext_vector_type(4)));
+                    ta4 o = {pj_cvt<TA>(acc[mt][j][0] + bv), pj_cvt<TA>(acc[mt][j][1] + bv), pj_cvt<TA>(acc[mt][j][2] + bv), pj_cvt<TA>(acc[mt][j][3] + bv)};
+                    *reinterpret_cast<ta4*>(hc + d * LINE + (mt * 16 + g * 4) * (int)sizeof(TA)) = o;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- cooperative store: every head chunk is 64 lines of 64 elements; 16 bytes per thread
+        constexpr int PPL = 64 * (int)sizeof(TA) / 16;        // 16-byte pieces per line (8 or 16)
+        constexpr int TOTALP = NHC * 64 * PPL;
+#pragma unroll
+        for (int i = 0; i < TOTALP / PTHREADS; ++i) {
+            const int idx = tid + PTHREADS * i;
+            const int piece = idx % PPL, line = (idx / PPL) & 63, hcl = idx / (PPL * 64);
+            const int hcg = pass * NHC + hcl;                 // global head chunk: group = hcg / 4, head = hcg & 3
+            const int group = hcg >> 2, head = hcg & 3;
+            const u32x4 val = *reinterpret_cast<const u32x4*>(smO + hcl * HCB + line * LINE + piece * 16);
+            TA* dst;
+            if (group < a.n_qk_groups) dst = static_cast<TA*>(group == 0 ? a.q : a.k) + ((long long)head * R + t.grow0 + line) * 64;   // line = row
+            else dst = static_cast<TA*>(a.vt) + ((long long)head * 64 + line) * R + t.grow0;                                            // line = d
+            *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(dst) + piece * 16) = val;
+        }
+    }
+}
+
+template <int PREC, class TA, int NTP, int NPASS> static hipError_t launch_proj_t(const ProjArgs& a, hipStream_t s) {
+    typedef typename PJ<PREC>::Tag Tag;
+    const int R = a.rs.B * (a.rs.cap0 + a.rs.cap1);
+    constexpr int STAGES = 256 / (8 * Tag::EPC);
+    constexpr int smem = PJ<PREC>::NPART * STAGES * PBM * 128 + NTP * 2 * 64 * (64 * (int)sizeof(TA) + 16);
+    auto kern = proj_kernel<PREC, TA, NTP, NPASS>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(R / PBM), dim3(PTHREADS), smem, s, a);
+    return hipGetLastError();
+}
+template <int PREC, class TA> static hipError_t launch_proj_n(const ProjArgs& a, hipStream_t s) {
+    if (a.Nout == 768) {
+        if constexpr (sizeof(TA) == 4) return launch_proj_t<PREC, TA, 2, 3>(a, s);
+        else return launch_proj_t<PREC, TA, 3, 2>(a, s);
+    }
+    if (a.Nout == 512) return launch_proj_t<PREC, TA, 2, 2>(a, s);
+    return hipErrorInvalidValue;
+}
+template <int PREC> static hipError_t launch_proj_p(int attn_prec, const ProjArgs& a, hipStream_t s) {
+    switch (attn_prec) {
+        case PREC_F32: return launch_proj_n<PREC, float>(a, s);
+        case PREC_BF16: return launch_proj_n<PREC, bf16_t>(a, s);
+        case PREC_F16: return launch_proj_n<PREC, f16_t>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t launch_proj(int prec, int attn_prec, const ProjArgs& a, hipStream_t s) {
+    switch (prec) {
+        case PREC_F32: return launch_proj_p<PREC_F32>(attn_prec, a, s);
+        case PREC_BF16: return launch_proj_p<PREC_BF16>(attn_prec, a, s);
+        case PREC_F16: return launch_proj_p<PREC_F16>(attn_prec, a, s);
+        case PREC_BF16X3: return launch_proj_p<PREC_BF16X3>(attn_prec, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace lg

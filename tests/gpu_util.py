@@ -67,6 +67,7 @@ def stage_errors(sd, data, precision, conf_kw, layer=0, fused=False):
         traces.append(tr)
     model = make_model(sd, precision, **conf_kw)
     model.set_option("fused_tail", int(fused))   # unfused: every intermediate buffer of the chain exists
+    model.set_option("fused_proj", int(fused))   # unfused: the generic GEMM with the QKV epilogue
     tdata = to_torch(data)
     res = {}
     L = layer

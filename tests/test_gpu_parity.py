@@ -96,6 +96,7 @@ def test_unfused_path_matches_golden():
     sd, data = make_golden.case_inputs(meta["case"])
     model = gpu_util.make_model(sd, "fp32", **meta["case"]["conf"])
     model.set_option("fused_tail", 0)
+    model.set_option("fused_proj", 0)
     out = model(gpu_util.to_torch(data))
     np.testing.assert_array_equal(out["matches0"].cpu().numpy(), gold["matches0"])
     np.testing.assert_allclose(out["matching_scores0"].cpu().numpy(), gold["matching_scores0"], atol=2e-4, rtol=0)

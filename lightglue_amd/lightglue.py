@@ -151,6 +151,7 @@ class LightGlue(nn.Module):
         self.static_lengths = None
         self._engine = None  # (handle, device_index, config signature)
         self._weights_sig = None
+        self._plist = None
         self.requires_grad_(False)
 
     # ------------------------------------------------------------------ weights
@@ -229,7 +230,15 @@ class LightGlue(nn.Module):
 
     def _sync_weights(self, handle, device):
         """Re-pack and upload whenever any parameter changed (load_state_dict, .to(), in-place edit)."""
-        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        # cheap change detector (runs every forward): in-place edits and load_state_dict bump `_version`,
+        # .to()/.cuda() move the storage
+        plist = self._plist
+        if plist is None:
+            plist = self._plist = list(self.parameters())
+        ver = 0
+        for p in plist:
+            ver += p._version
+        sig = (ver, plist[0].data_ptr(), plist[-1].data_ptr(), len(plist))
         if sig == self._weights_sig:
             return
         lib = _cabi.load()
@@ -327,22 +336,25 @@ class LightGlue(nn.Module):
         if getattr(self, "_debug_step", -1) >= 0:  # test tap: the pipeline stopped early, outputs are not written
             torch.cuda.synchronize(device)
             return None
-        # ---- output assembly (ref :593-629)
-        counts = n_matches.tolist()  # the one host synchronisation of the forward (ragged lists need sizes)
-        matches = [mlist[k, : counts[k]].long() for k in range(b)]
-        mscores = [mscore_list[k, : counts[k]] for k in range(b)]
+        # ---- output assembly (ref :593-629).  Everything that does not need the ragged sizes is enqueued BEFORE
+        # the one host synchronisation of the forward, so the GPU is never idle waiting for Python.
+        m0_64, m1_64, mlist64 = m0.long(), m1.long(), mlist.long()
         if do_point_pruning:
             prune0, prune1 = prune0.long(), prune1.long()
         else:  # ref :616-617
-            prune0 = torch.ones_like(ms0) * conf.n_layers
-            prune1 = torch.ones_like(ms1) * conf.n_layers
+            prune0 = torch.full_like(ms0, float(conf.n_layers))
+            prune1 = torch.full_like(ms1, float(conf.n_layers))
+        stop64 = stop.long() if b > 1 else None
+        counts = n_matches.tolist()  # host sync: the ragged lists need their sizes
+        matches = [mlist64[k, : counts[k]] for k in range(b)]
+        mscores = [mscore_list[k, : counts[k]] for k in range(b)]
         if not do_early_stop and m > 0 and n > 0:
             stop_out = conf.n_layers if b == 1 else torch.full((b,), conf.n_layers, device=device, dtype=torch.long)
         else:
-            stop_out = int(stop[0].item()) if b == 1 else stop.long()
+            stop_out = int(stop[0].item()) if b == 1 else stop64
         return {
-            "matches0": m0.long(),
-            "matches1": m1.long(),
+            "matches0": m0_64,
+            "matches1": m1_64,
             "matching_scores0": ms0,
             "matching_scores1": ms1,
             "stop": stop_out,

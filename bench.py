@@ -61,6 +61,16 @@ def flops_per_launch(pairs: int, n: int, m: int):
     }
 
 
+# HBM bytes per launch of the dominant kernel measured with rocprofv3 PMC passes (FETCH_SIZE x 2 per the gfx950
+# correction in MI355X_MICROARCH.md + WRITE_SIZE), profiles/r01b_pmc_{fetch,write}.md; valid for the default workload only.
+PMC_TRAFFIC_BYTES = {("bf16x3", 32, 1024, "fused_tail"): (2 * 1.199e5 + 6.554e4) * 1024}
+
+
+def hbm_bytes_assign(pairs: int, n: int, m: int) -> float:
+    """two fp32 read sweeps of the similarity matrix (row/column LSE, then score/argmax)."""
+    return pairs * 8.0 * n * m
+
+
 def flops_per_pair(n: int, m: int) -> float:
     """80.53 GFLOP at n = m = 1024 (shared-S accounting for cross attention)."""
     per_pt_layer = 1_310_720 + 1_179_648
@@ -192,8 +202,14 @@ def main():
                                    + (" (split-bf16 MFMA x3 for linear layers + f16 attention, fp32 accumulate/residual)" if args.precision == "bf16x3" else ""),
                        "pairs_per_gpu": B, "keypoints": n, "parallelism": f"pair-sharded dp{world}"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None, "avg_launch_ms": dom_ms, "algorithmic_flops_per_launch": fl[dom],
+                         "traffic": PMC_TRAFFIC_BYTES.get((args.precision, B, n, dom)), "avg_launch_ms": dom_ms, "algorithmic_flops_per_launch": fl[dom],
                          "note": "algorithmic FLOPs (2/MAC) of one launch / HIP-event launch duration; split-bf16 issues 3 MFMAs per algorithmic MAC"},
+            # the HBM-bound stage of the path: dual log-softmax + argmax sweeps over the similarity matrix
+            "roofline_hbm": ({"bound": "hbm", "kernel": "assign (lse_sweep + argmax_sweep + merges + finalize)",
+                              "achieved": hbm_bytes_assign(B, n, m) / (timed["assign"][0] / timed["assign"][1] * 1e-3) / 1e9,
+                              "peak": 8000.0, "unit": "GB/s",
+                              "frac": hbm_bytes_assign(B, n, m) / (timed["assign"][0] / timed["assign"][1] * 1e-3) / 1e9 / 8000.0,
+                              "algorithmic_bytes_per_launch": hbm_bytes_assign(B, n, m)} if "assign" in timed else None),
             "kernel_ms_per_step": kernel_ms,
             "gpu_ms_per_step_sum": round(sum(kernel_ms.values()), 3),
             "algorithmic_tflops": value * flops_per_pair(n, m) / 1e12,

@@ -2,9 +2,10 @@
 // sigmoid_log_double_softmax, :302-318 filter_matches, :593-614 output assembly).
 // The similarity matrix sim[pair][a][b] (fp32) is produced by launch_sim; everything here is
 // HBM-bound streaming over it:
-//   pass 1  row log-sum-exp (one wave per row) and column log-sum-exp (64-column strips)
-//   pass 2  score(a,b) = ((sim - lse_r[a]) + (sim - lse_c[b])) + (ls0[a] + ls1[b])   [ref :270-274]
-//           row max/argmax and column max/argmax with first-index tie-break (torch.max semantics)
+//   sweep 1 row log-sum-exp and per-row-tile column (max, sum-exp) partials in ONE pass over sim
+//   sweep 2 score(a,b) = ((sim - lse_r[a]) + (sim - lse_c[b])) + (ls0[a] + ls1[b])   [ref :270-274] on the fly;
+//           row max/argmax and per-row-tile column max/argmax partials, first-index tie-break (torch.max)
+//           => 8*N*M algorithmic bytes per pair (two fp32 read sweeps) + 1/8 of that in partials
 //   final   mutual check, exp, threshold, scatter through the index sets into ORIGINAL index
 //           space (un-pruning, ref :605-614) and the compact sorted match list (ref :593-602).
 // The dustbin row/column (ref :275-276) never influence any output of forward and
@@ -13,118 +14,169 @@
 
 namespace lg {
 
+// exp via the bare v_exp_f32 (arguments are <= 0 here; a flushed tail term is below fp32 resolution of the sum)
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
 __device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
     const float mn = fmaxf(m, m2);
     if (mn == -INFINITY) { m = mn; s = 0.f; return; }
-    s = s * expf(m - mn) + s2 * expf(m2 - mn);
+    s = s * fexp(m - mn) + s2 * fexp(m2 - mn);
     m = mn;
 }
 
-// ---- pass 1a: row LSE.  grid (cap0/4, B), one wave per row
-__global__ __launch_bounds__(256) void row_lse_kernel(AssignArgs a) {
-    const int pair = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + wave;
+// Both sweeps use the same decomposition: workgroup = ART rows x all columns; thread = 4 consecutive
+// columns (one float4 per row, a wave reads 1 KB contiguous), looping over the tile's rows and, for
+// n > 1024, over column passes.  Row statistics are per-thread partials reduced across the workgroup at
+// the end; column statistics are per-row-tile partials [tile][column] merged by the next kernel.
+constexpr int ART = 32;
+
+// ---- sweep 1: row log-sum-exp + column (max, sum-exp) partials.  grid (cap0/ART, B)
+__global__ __launch_bounds__(256) void lse_sweep_kernel(AssignArgs a) {
+    const int pair = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int len0 = a.rs.len[2 * pair], len1 = a.rs.len[2 * pair + 1];
-    if (r >= len0) return;
-    const float* row = a.sim + ((long long)pair * a.rs.cap0 + r) * a.rs.cap1;
-    float m = -INFINITY;
-    for (int c = lane * 4; c < len1; c += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+    const int r0 = tile * ART;
+    if (r0 >= len0) return;
+    const int ntiles = a.rs.cap0 / ART;
+    const float* simp = a.sim + ((long long)pair * a.rs.cap0 + r0) * a.rs.cap1;
+    float* pm = a.cpm + ((long long)pair * ntiles + tile) * a.rs.cap1;
+    float* ps = a.cps + ((long long)pair * ntiles + tile) * a.rs.cap1;
+    float rm[ART], rsum[ART];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (c + i < len1) m = fmaxf(m, v[i]);
-    }
-    m = wave_max(m);
-    float s = 0.f;
-    for (int c = lane * 4; c < len1; c += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+    for (int r = 0; r < ART; ++r) { rm[r] = -INFINITY; rsum[r] = 0.f; }
+    for (int c = tid * 4; c < len1; c += 1024) {
+        float cm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (c + i < len1) s += expf(v[i] - m);
+        for (int r = 0; r < ART; ++r) {
+            if (r0 + r < len0) {   // workgroup-uniform
+                f32x4 v = *reinterpret_cast<const f32x4*>(simp + (long long)r * a.rs.cap1 + c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (c + i >= len1) v[i] = -INFINITY;
+                const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));   // finite: column c itself is live
+                const float mn = fmaxf(rm[r], m4);
+                rsum[r] = rsum[r] * fexp(rm[r] - mn) + (fexp(v[0] - mn) + fexp(v[1] - mn)) + (fexp(v[2] - mn) + fexp(v[3] - mn));
+                rm[r] = mn;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (v[i] > cm[i]) { cs[i] = cs[i] * fexp(cm[i] - v[i]) + 1.f; cm[i] = v[i]; }
+                    else cs[i] += fexp(v[i] - cm[i]);
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(pm + c) = f32x4{cm[0], cm[1], cm[2], cm[3]};
+        *reinterpret_cast<f32x4*>(ps + c) = f32x4{cs[0], cs[1], cs[2], cs[3]};
     }
-    s = wave_sum(s);
-    if (lane == 0) a.lse_r[(long long)pair * a.rs.cap0 + r] = m + logf(s);
+    // row reduction across the workgroup: wave-level first (DPP/permute), then 4 waves through LDS
+    __shared__ float shm[4][ART], shs[4][ART];
+#pragma unroll
+    for (int r = 0; r < ART; ++r) {
+        float m = rm[r], s = rsum[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+            lse_merge(m, s, m2, s2);
+        }
+        if (lane == 0) { shm[wave][r] = m; shs[wave][r] = s; }
+    }
+    __syncthreads();
+    if (tid < ART && r0 + tid < len0) {
+        float m = shm[0][tid], s = shs[0][tid];
+        for (int w = 1; w < 4; ++w) lse_merge(m, s, shm[w][tid], shs[w][tid]);
+        a.lse_r[(long long)pair * a.rs.cap0 + r0 + tid] = m + logf(s);
+    }
 }
 
-// ---- pass 1b: column LSE.  grid (cap1/64, B); thread = (column lane, row group of 4)
-__global__ __launch_bounds__(256) void col_lse_kernel(AssignArgs a) {
-    const int pair = blockIdx.y, cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+// ---- merge the column partials: lse_c[b] over the live row tiles.  grid (cap1/256, B)
+__global__ __launch_bounds__(256) void col_lse_merge_kernel(AssignArgs a) {
+    const int pair = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
     const int len0 = a.rs.len[2 * pair], len1 = a.rs.len[2 * pair + 1];
-    const int c = blockIdx.x * 64 + cl;
-    if (blockIdx.x * 64 >= len1) return;
-    const float* simp = a.sim + (long long)pair * a.rs.cap0 * a.rs.cap1 + c;
+    if (c >= len1) return;
+    const int ntiles = a.rs.cap0 / ART, live = (len0 + ART - 1) / ART;
+    const float* pm = a.cpm + (long long)pair * ntiles * a.rs.cap1 + c;
+    const float* ps = a.cps + (long long)pair * ntiles * a.rs.cap1 + c;
     float m = -INFINITY, s = 0.f;
-    for (int r = rg; r < len0; r += 4) {
-        const float v = simp[(long long)r * a.rs.cap1];
-        if (v > m) { s = s * expf(m - v) + 1.f; m = v; } else s += expf(v - m);
-    }
-    __shared__ float shm[4][64], shs[4][64];
-    shm[rg][cl] = m; shs[rg][cl] = s;
-    __syncthreads();
-    if (rg == 0 && c < len1) {
-        for (int i = 1; i < 4; ++i) lse_merge(m, s, shm[i][cl], shs[i][cl]);
-        a.lse_c[(long long)pair * a.rs.cap1 + c] = m + logf(s);
-    }
+    for (int t = 0; t < live; ++t) lse_merge(m, s, pm[(long long)t * a.rs.cap1], ps[(long long)t * a.rs.cap1]);
+    a.lse_c[(long long)pair * a.rs.cap1 + c] = m + logf(s);
 }
 
 __device__ __forceinline__ float score_of(float sim, float lr, float lc, float cert) {
     return ((sim - lr) + (sim - lc)) + cert;   // ref :271-274 evaluation order
 }
 
-// ---- pass 2a: row max / argmax of the score matrix.  one wave per row
-__global__ __launch_bounds__(256) void row_argmax_kernel(AssignArgs a) {
-    const int pair = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + wave;
+// ---- sweep 2: score matrix on the fly; row max/argmax (final) + column max/argmax partials per row tile
+__global__ __launch_bounds__(256) void argmax_sweep_kernel(AssignArgs a) {
+    const int pair = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int len0 = a.rs.len[2 * pair], len1 = a.rs.len[2 * pair + 1];
-    if (r >= len0) return;
-    const float* row = a.sim + ((long long)pair * a.rs.cap0 + r) * a.rs.cap1;
+    const int r0 = tile * ART;
+    if (r0 >= len0) return;
+    const int ntiles = a.rs.cap0 / ART;
+    const float* simp = a.sim + ((long long)pair * a.rs.cap0 + r0) * a.rs.cap1;
     const float* lsec = a.lse_c + (long long)pair * a.rs.cap1;
     const float* ls1 = a.ls + seg_row_base(a.rs, 2 * pair + 1);
-    const float lr = a.lse_r[(long long)pair * a.rs.cap0 + r];
-    const float l0 = a.ls[seg_row_base(a.rs, 2 * pair) + r];
-    float best = -INFINITY; int bi = 0x7fffffff;
-    for (int c = lane * 4; c < len1; c += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+    const float* lser = a.lse_r + (long long)pair * a.rs.cap0 + r0;
+    const float* ls0 = a.ls + seg_row_base(a.rs, 2 * pair) + r0;
+    float* pv = a.cbv + ((long long)pair * ntiles + tile) * a.rs.cap1;
+    int* pi = a.cbi + ((long long)pair * ntiles + tile) * a.rs.cap1;
+    float rb[ART]; int ri[ART];
+#pragma unroll
+    for (int r = 0; r < ART; ++r) { rb[r] = -INFINITY; ri[r] = 0x7fffffff; }
+    for (int c = tid * 4; c < len1; c += 1024) {
         const f32x4 lc = *reinterpret_cast<const f32x4*>(lsec + c);
         const f32x4 l1 = *reinterpret_cast<const f32x4*>(ls1 + c);
+        float cb[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}; int ci[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (c + i < len1) {
-            const float sc = score_of(v[i], lr, lc[i], l0 + l1[i]);
-            if (sc > best || (sc == best && c + i < bi)) { best = sc; bi = c + i; }
+        for (int r = 0; r < ART; ++r) {
+            if (r0 + r < len0) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(simp + (long long)r * a.rs.cap1 + c);
+                const float lr = lser[r], l0 = ls0[r];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (c + i < len1) {
+                        const float sc = score_of(v[i], lr, lc[i], l0 + l1[i]);
+                        if (sc > rb[r]) { rb[r] = sc; ri[r] = c + i; }          // ascending columns per thread: first index wins
+                        if (sc > cb[i]) { cb[i] = sc; ci[i] = r0 + r; }          // ascending rows: first index wins
+                    }
+                }
+            }
         }
+        *reinterpret_cast<f32x4*>(pv + c) = f32x4{cb[0], cb[1], cb[2], cb[3]};
+        *reinterpret_cast<int4*>(pi + c) = int4{ci[0], ci[1], ci[2], ci[3]};
     }
+    __shared__ float shb[4][ART]; __shared__ int shi[4][ART];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    }
-    if (lane == 0) { a.max0[(long long)pair * a.rs.cap0 + r] = best; a.arg0[(long long)pair * a.rs.cap0 + r] = bi; }
-}
-
-// ---- pass 2b: column max / argmax.  grid (cap1/64, B)
-__global__ __launch_bounds__(256) void col_argmax_kernel(AssignArgs a) {
-    const int pair = blockIdx.y, cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int len0 = a.rs.len[2 * pair], len1 = a.rs.len[2 * pair + 1];
-    const int c = blockIdx.x * 64 + cl;
-    if (blockIdx.x * 64 >= len1) return;
-    const float* simp = a.sim + (long long)pair * a.rs.cap0 * a.rs.cap1 + c;
-    const float* lser = a.lse_r + (long long)pair * a.rs.cap0;
-    const float* ls0 = a.ls + seg_row_base(a.rs, 2 * pair);
-    const float lc = c < len1 ? a.lse_c[(long long)pair * a.rs.cap1 + c] : 0.f;
-    const float l1 = c < len1 ? a.ls[seg_row_base(a.rs, 2 * pair + 1) + c] : 0.f;
-    float best = -INFINITY; int bi = 0x7fffffff;
-    for (int r = rg; r < len0; r += 4) {   // ascending r per thread: strict '>' keeps the first index
-        const float sc = score_of(simp[(long long)r * a.rs.cap1], lser[r], lc, ls0[r] + l1);
-        if (sc > best) { best = sc; bi = r; }
-    }
-    __shared__ float shb[4][64]; __shared__ int shi[4][64];
-    shb[rg][cl] = best; shi[rg][cl] = bi;
-    __syncthreads();
-    if (rg == 0 && c < len1) {
-        for (int i = 1; i < 4; ++i) {
-            const float ob = shb[i][cl]; const int oi = shi[i][cl];
+    for (int r = 0; r < ART; ++r) {
+        float best = rb[r]; int bi = ri[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
             if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
         }
-        a.max1[(long long)pair * a.rs.cap1 + c] = best; a.arg1[(long long)pair * a.rs.cap1 + c] = bi;
+        if (lane == 0) { shb[wave][r] = best; shi[wave][r] = bi; }
     }
+    __syncthreads();
+    if (tid < ART && r0 + tid < len0) {
+        float best = shb[0][tid]; int bi = shi[0][tid];
+        for (int w = 1; w < 4; ++w) {
+            const float ob = shb[w][tid]; const int oi = shi[w][tid];
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        a.max0[(long long)pair * a.rs.cap0 + r0 + tid] = best; a.arg0[(long long)pair * a.rs.cap0 + r0 + tid] = bi;
+    }
+}
+
+// ---- merge the column argmax partials (ascending row tiles, strict '>': first index).  grid (cap1/256, B)
+__global__ __launch_bounds__(256) void col_argmax_merge_kernel(AssignArgs a) {
+    const int pair = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    const int len0 = a.rs.len[2 * pair], len1 = a.rs.len[2 * pair + 1];
+    if (c >= len1) return;
+    const int ntiles = a.rs.cap0 / ART, live = (len0 + ART - 1) / ART;
+    const float* pv = a.cbv + (long long)pair * ntiles * a.rs.cap1 + c;
+    const int* pi = a.cbi + (long long)pair * ntiles * a.rs.cap1 + c;
+    float best = -INFINITY; int bi = 0;
+    for (int t = 0; t < live; ++t) {
+        const float v = pv[(long long)t * a.rs.cap1];
+        if (v > best) { best = v; bi = pi[(long long)t * a.rs.cap1]; }
+    }
+    a.max1[(long long)pair * a.rs.cap1 + c] = best; a.arg1[(long long)pair * a.rs.cap1 + c] = bi;
 }
 
 // ---- final: one workgroup per pair
@@ -193,10 +245,10 @@ hipError_t launch_assign(const AssignArgs& a, hipStream_t s) {
         if ((e = hipMemsetAsync(a.m1, 0xFF, sizeof(int) * (size_t)B * a.n1, s)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(a.s1, 0, sizeof(float) * (size_t)B * a.n1, s)) != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(row_lse_kernel, dim3(a.rs.cap0 / 4, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(col_lse_kernel, dim3(a.rs.cap1 / 64, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(row_argmax_kernel, dim3(a.rs.cap0 / 4, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(col_argmax_kernel, dim3(a.rs.cap1 / 64, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(lse_sweep_kernel, dim3(a.rs.cap0 / ART, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(col_lse_merge_kernel, dim3((a.rs.cap1 + 255) / 256, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(argmax_sweep_kernel, dim3(a.rs.cap0 / ART, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(col_argmax_merge_kernel, dim3((a.rs.cap1 + 255) / 256, B), dim3(256), 0, s, a);
     hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -100,7 +100,8 @@ struct lg_engine {
     int capB = 0, cap0 = 0, cap1 = 0;      // reserved
     int cur_cap0 = 0, cur_cap1 = 0, curB = 0;
     std::map<std::string, std::pair<void*, size_t>> bufs;
-    float *X, *CTX, *MSG, *H1, *G, *COS, *SIN, *MD, *SIM, *LS, *CONF, *MSCORE, *LSE_R, *LSE_C, *MAX0, *MAX1, *BBOX, *XIN;
+    float *X, *CTX, *MSG, *H1, *G, *COS, *SIN, *MD, *SIM, *LS, *CONF, *MSCORE, *LSE_R, *LSE_C, *MAX0, *MAX1, *BBOX, *XIN, *CPM, *CPS, *CBV;
+    int* CBI;
     void *Q, *K, *VT;
     int *IND, *DST, *LEN, *LEN_OLD, *ACTIVE, *FINAL_LAYER, *ARG0, *ARG1;
     int debug_stop = -1;
@@ -200,6 +201,7 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
         add((size_t)nB * nc0 * 4); add((size_t)nB * nc1 * 4);   // LSE_R LSE_C
         add((size_t)nB * nc0 * 4); add((size_t)nB * nc1 * 4);   // MAX0 MAX1
         add((size_t)nB * nc0 * 4); add((size_t)nB * nc1 * 4);   // ARG0 ARG1
+        for (int i = 0; i < 4; ++i) add((size_t)nB * (nc0 / 32) * nc1 * 4);   // CPM CPS CBV CBI
         add((size_t)nB * 8 * 4);                                // BBOX
         add(R * (size_t)e->cfg.input_dim * 4);                  // XIN
         for (int i = 0; i < 3; ++i) add(R * 256 * as);          // Q K VT
@@ -226,6 +228,8 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
     e->LSE_R = (float*)take("LSE_R", (size_t)B * c0 * 4); e->LSE_C = (float*)take("LSE_C", (size_t)B * c1 * 4);
     e->MAX0 = (float*)take("MAX0", (size_t)B * c0 * 4); e->MAX1 = (float*)take("MAX1", (size_t)B * c1 * 4);
     e->ARG0 = (int*)take("ARG0", (size_t)B * c0 * 4); e->ARG1 = (int*)take("ARG1", (size_t)B * c1 * 4);
+    e->CPM = (float*)take("CPM", (size_t)B * (c0 / 32) * c1 * 4); e->CPS = (float*)take("CPS", (size_t)B * (c0 / 32) * c1 * 4);
+    e->CBV = (float*)take("CBV", (size_t)B * (c0 / 32) * c1 * 4); e->CBI = (int*)take("CBI", (size_t)B * (c0 / 32) * c1 * 4);
     e->BBOX = (float*)take("BBOX", (size_t)B * 8 * 4);
     e->XIN = (float*)take("XIN", R * (size_t)e->cfg.input_dim * 4);
     e->Q = take("Q", R * 256 * as); e->K = take("K", R * 256 * as); e->VT = take("VT", R * 256 * as);
@@ -701,7 +705,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
         TRY(prof_end(e, s));
         AssignArgs as{};
         as.rs = rs_all; as.sim = e->SIM; as.ls = e->LS; as.lse_r = e->LSE_R; as.lse_c = e->LSE_C; as.max0 = e->MAX0; as.arg0 = e->ARG0;
-        as.max1 = e->MAX1; as.arg1 = e->ARG1; as.ind = e->IND; as.n0 = n0; as.n1 = n1; as.filter_threshold = (float)e->cfg.filter_threshold;
+        as.max1 = e->MAX1; as.arg1 = e->ARG1; as.cpm = e->CPM; as.cps = e->CPS; as.cbv = e->CBV; as.cbi = e->CBI; as.ind = e->IND; as.n0 = n0; as.n1 = n1; as.filter_threshold = (float)e->cfg.filter_threshold;
         as.m0 = io->matches0; as.m1 = io->matches1; as.s0 = io->scores0; as.s1 = io->scores1;
         as.matches = io->matches; as.mscores = io->match_scores; as.n_matches = io->n_matches; as.max_matches = max_matches;
         TRY(prof_begin(e, PC_ASSIGN, s));

@@ -131,6 +131,8 @@ struct AssignArgs {
     float* lse_r; float* lse_c;          // [B][cap0], [B][cap1]
     float* max0; int* arg0;  // [B][cap0] row max / argmax of the score matrix
     float* max1; int* arg1;  // [B][cap1]
+    float* cpm; float* cps;  // [B][cap0/32][cap1] column (max, sum-exp) partials per 32-row tile
+    float* cbv; int* cbi;    // [B][cap0/32][cap1] column (best score, row) partials per 32-row tile
     const int* ind;          // [R]
     int n0, n1;
     float filter_threshold;

@@ -82,3 +82,25 @@ def test_product_code_never_imports_the_oracle():
     for f in list(pkg.glob("*.py")) + list((pkg / "csrc").glob("*")):
         if f.is_file() and f.suffix in (".py", ".hip", ".h"):
             assert "oracle" not in f.read_text().replace("no CPU / PyTorch fallback", ""), f
+
+
+def test_utils_glue_mirrors_reference():
+    """rbd / batch_to_device / match_pair (ref utils.py:55-69, 150-165) with a stub extractor and matcher."""
+    from lightglue_amd import batch_to_device, match_pair, rbd
+
+    class Ext:
+        def extract(self, img, **kw):
+            n = int(img.sum().item())
+            return {"keypoints": torch.rand(1, n, 2), "descriptors": torch.rand(1, n, 256), "image_size": torch.tensor([[640.0, 480.0]])}
+
+    def matcher(d):
+        m = d["image0"]["keypoints"].shape[1]
+        return {"matches0": torch.full((1, m), -1), "matches": [torch.zeros((0, 2), dtype=torch.long)], "stop": 9}
+
+    f0, f1, m01 = match_pair(Ext(), matcher, torch.ones(5), torch.ones(7), device="cpu")
+    assert f0["keypoints"].shape == (5, 2) and f1["descriptors"].shape == (7, 256)
+    assert m01["matches0"].shape == (5,) and m01["matches"].shape == (0, 2) and m01["stop"] == 9
+    d = rbd({"a": torch.zeros(1, 3), "b": [torch.ones(2)], "c": 4})
+    assert d["a"].shape == (3,) and d["b"].shape == (2,) and d["c"] == 4
+    moved = batch_to_device({"x": {"y": torch.zeros(2)}, "s": "name"}, "cpu")
+    assert moved["s"] == "name" and moved["x"]["y"].device.type == "cpu"

@@ -123,11 +123,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # debugging aid: LG_BENCH_BACKEND=gloo LG_BENCH_ONE_GPU=1 runs several ranks on cuda:0 (flow test without a node)
+    backend = os.environ.get("LG_BENCH_BACKEND", "nccl")
+    if os.environ.get("LG_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)

@@ -486,7 +486,7 @@ int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
     if (!e || !key) return fail(LG_ERR_INVALID, "null argument");
     if (std::strcmp(key, "fused_tail") == 0) { e->fused_tail = value != 0; return LG_OK; }
     if (std::strcmp(key, "fused_proj") == 0) { e->fused_proj = value != 0; return LG_OK; }
-    if (std::strcmp(key, "tail_timing") == 0) { e->tail_timing = value != 0; return LG_OK; }
+    if (std::strcmp(key, "tail_timing") == 0) { e->tail_timing = value; return LG_OK; }   // 1: tail kernel, 2: self projection
     return fail(LG_ERR_INVALID, std::string("unknown option '") + key + "'");
 }
 
@@ -586,6 +586,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 pj.bias = blk == 0 ? e->b_sqkv + (size_t)i * 768 : e->b_cqkv + (size_t)i * 512;
                 pj.Nout = blk == 0 ? 768 : 512; pj.n_qk_groups = blk == 0 ? 2 : 1;
                 pj.cosb = blk == 0 ? e->COS : nullptr; pj.sinb = blk == 0 ? e->SIN : nullptr;
+                pj.dbg = (e->tail_timing == 2 && blk == 0) ? e->TAILDBG : nullptr;
                 TRY(prof_begin(e, blk == 0 ? PC_GEMM_QKV_SELF : PC_GEMM_QKV_CROSS, s));
                 HIPCHK(launch_proj(prec, ap, pj, s));
                 TRY(prof_end(e, s));
@@ -616,7 +617,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 ta.gamma = (blk ? e->ln_c_g : e->ln_s_g) + (size_t)i * 512; ta.beta = (blk ? e->ln_c_b : e->ln_s_b) + (size_t)i * 512;
                 ta.W2 = (blk ? e->w_ctail_2 : e->w_stail_2) + (size_t)i * e->tail_2_layer_bytes;
                 ta.b2 = (blk ? e->b_cf2 : e->b_sf2) + (size_t)i * D;
-                ta.dbg = e->tail_timing ? e->TAILDBG : nullptr;
+                ta.dbg = e->tail_timing == 1 ? e->TAILDBG : nullptr;
                 TRY(prof_begin(e, PC_TAIL, s));
                 HIPCHK(launch_tail(prec, ta, s));
                 TRY(prof_end(e, s));

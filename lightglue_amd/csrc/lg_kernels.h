@@ -65,6 +65,7 @@ struct ProjArgs {
     void* q; void* k; void* vt;                      // q,k: [H][R][64]   vt: [H][64][R]
     const float* cosb; const float* sinb;            // rotary tables [R][32] or nullptr
     int n_qk_groups; int R;
+    long long* dbg;                                  // profiling tap: [blocks][8 waves][8] shader-clock stamps, or nullptr
 };
 hipError_t launch_proj(int prec, int attn_prec, const ProjArgs& a, hipStream_t s);
 

@@ -45,17 +45,32 @@ __global__ __launch_bounds__(PTHREADS) void proj_kernel(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* smA = smem;                         // [NPART][STAGES][64][128 B]
     char* smO = smem + NPART * A_PLANE;       // [NHC][64 lines][LINE]
+    float* smCS = reinterpret_cast<float*>(smO + NHC * HCB);   // rotary tables of the tile: cos [64][32], sin [64][32]
 
     const TileLoc t = locate_tile(a.rs, blockIdx.x, PBM);
     if (t.r0 >= a.rs.len[t.seg]) return;
     if (a.rs.active && !a.rs.active[t.pair]) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
     const long long R = a.R;
+    auto stamp = [&](int slot) {   // profiling tap (a.dbg == nullptr in production)
+        if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8 + slot] = clock64();
+    };
+    stamp(0);
 
     auto wfrag = [&](int p, int nt, int kc) -> u32x4 {
         const char* ptr = static_cast<const char*>(a.W) + (p ? (long long)a.Nout * 256 * (long long)sizeof(typename Tag::elem) : 0);
         return *reinterpret_cast<const u32x4*>(ptr + ((long long)(nt * NKC + kc) * 64 + lane) * 16);
     };
+    // ---- rotary tables of the tile -> LDS (two coalesced 16-byte loads per thread; the epilogue used to issue
+    //      ~100 dependent 4-byte global loads per lane for them, 45 % of the kernel)
+    const bool rope = a.cosb != nullptr;
+    if (rope) {
+        const int i = tid;                      // 512 threads x float4 = 64 rows x 32 floats
+        const f32x4 c4 = *reinterpret_cast<const f32x4*>(a.cosb + (long long)t.grow0 * 32 + i * 4);
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.sinb + (long long)t.grow0 * 32 + i * 4);
+        *reinterpret_cast<f32x4*>(smCS + i * 4) = c4;
+        *reinterpret_cast<f32x4*>(smCS + 2048 + i * 4) = s4;
+    }
     // ---- activation tile: HBM -> registers -> operand precision -> LDS (once)
     {
         const int srow = tid >> 3, sslot = tid & 7;
@@ -92,6 +107,7 @@ __global__ __launch_bounds__(PTHREADS) void proj_kernel(ProjArgs a) {
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i) load_b(bf[i], 0, i);
     __syncthreads();
+    stamp(1);
 
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
@@ -130,6 +146,7 @@ __global__ __launch_bounds__(PTHREADS) void proj_kernel(ProjArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        stamp(2 + 3 * pass);
         // ---- epilogue of the pass: bias, rotary, stage through LDS
         if (pass > 0) __syncthreads();    // the previous pass's staged tile has been fully read
 #pragma unroll
@@ -141,7 +158,6 @@ __global__ __launch_bounds__(PTHREADS) void proj_kernel(ProjArgs a) {
             const float bv = a.bias[col0 + lr];
             char* hc = smO + hcl * HCB;
             if (group < a.n_qk_groups) {   // q / k (or qk): [row][64], written as (even, odd) column pairs
-                const bool rope = a.cosb != nullptr;
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     float v[4];
@@ -149,9 +165,9 @@ __global__ __launch_bounds__(PTHREADS) void proj_kernel(ProjArgs a) {
                     for (int r = 0; r < 4; ++r) {
                         v[r] = acc[mt][j][r] + bv;
                         if (rope) {   // ref :58-65: pairs are adjacent columns = adjacent lanes
-                            const long long row = t.grow0 + mt * 16 + g * 4 + r;
+                            const int lrow = mt * 16 + g * 4 + r;
                             const float other = dpp_xor1(v[r]);
-                            const float c = a.cosb[row * 32 + (d >> 1)], s = a.sinb[row * 32 + (d >> 1)];
+                            const float c = smCS[lrow * 32 + (d >> 1)], s = smCS[2048 + lrow * 32 + (d >> 1)];
                             v[r] = (d & 1) ? (v[r] * c + other * s) : (v[r] * c - other * s);
                         }
                     }
@@ -183,6 +199,7 @@ __global__ __launch_bounds__(PTHREADS) void proj_kernel(ProjArgs a) {
             }
         }
         __syncthreads();
+        stamp(3 + 3 * pass);
         // ---- cooperative store: every head chunk is 64 lines of 64 elements; 16 bytes per thread
         constexpr int PPL = 64 * (int)sizeof(TA) / 16;        // 16-byte pieces per line (8 or 16)
         constexpr int TOTALP = NHC * 64 * PPL;
@@ -198,6 +215,7 @@ __global__ __launch_bounds__(PTHREADS) void proj_kernel(ProjArgs a) {
             else dst = static_cast<TA*>(a.vt) + ((long long)head * 64 + line) * R + t.grow0;                                            // line = d
             *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(dst) + piece * 16) = val;
         }
+        stamp(4 + 3 * pass);
     }
 }
 
@@ -205,7 +223,7 @@ template <int PREC, class TA, int NTP, int NPASS> static hipError_t launch_proj_
     typedef typename PJ<PREC>::Tag Tag;
     const int R = a.rs.B * (a.rs.cap0 + a.rs.cap1);
     constexpr int STAGES = 256 / (8 * Tag::EPC);
-    constexpr int smem = PJ<PREC>::NPART * STAGES * PBM * 128 + NTP * 2 * 64 * (64 * (int)sizeof(TA) + 16);
+    constexpr int smem = PJ<PREC>::NPART * STAGES * PBM * 128 + NTP * 2 * 64 * (64 * (int)sizeof(TA) + 16) + 2 * 64 * 32 * 4;
     auto kern = proj_kernel<PREC, TA, NTP, NPASS>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;

@@ -80,8 +80,14 @@ class PairShardedMatcher:
             buf[:nloc, 2 * m + n:2 * m + 2 * n] = out["matching_scores1"].to(torch.float32).contiguous().view(torch.int32)
             buf[:nloc, -1] = stop_t
         if world > 1:
-            gathered = torch.empty((world * per_rank, width), dtype=torch.int32, device=dev)
-            dist.all_gather_into_tensor(gathered, buf, group=self.group)
+            # RCCL ("nccl") gathers device buffers directly; gloo (CPU tests, or a debugging run of several ranks
+            # on one GPU) goes through host copies
+            via_host = dist.get_backend(self.group) == "gloo" and buf.is_cuda
+            send = buf.cpu() if via_host else buf
+            gathered = torch.empty((world * per_rank, width), dtype=torch.int32, device=send.device)
+            dist.all_gather_into_tensor(gathered, send, group=self.group)
+            if via_host:
+                gathered = gathered.to(dev)
             rows = []
             for r in range(world):
                 rlo, rhi = shard_range(global_batch, r, world)

@@ -8,17 +8,19 @@ sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import gpu_util
 from lightglue_amd import synthetic as synth
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
+which = int(sys.argv[2]) if len(sys.argv) > 2 else 1   # 1 = fused tail, 2 = self projection
 sd = synth.make_state_dict(0, recipe="A")
 model = gpu_util.make_model(sd, prec, depth_confidence=-1, width_confidence=-1)
 data = gpu_util.to_torch(synth.make_batch(1, 32, 1024, 1024))
-model(data); model.set_option("tail_timing", 1); model(data); torch.cuda.synchronize()
-d = model.debug_read("TAILDBG", np.int64).reshape(-1, 8, 8)[:, :, :6]
+model(data); model.set_option("tail_timing", which); model(data); torch.cuda.synchronize()
+nst = 6 if which == 1 else 8
+d = model.debug_read("TAILDBG", np.int64).reshape(-1, 8, 8)[:, :, :nst]
 dt = np.diff(d, axis=2).astype(np.float64)
-names = ["phaseA", "LN+GELU", "g->LDS", "phaseB", "epilogue"]
+names = ["phaseA", "LN+GELU", "g->LDS", "phaseB", "epilogue"] if which == 1 else ["A tile -> LDS", "pass0 MFMA", "pass0 bias/rope/stage", "pass0 store", "pass1 MFMA", "pass1 stage", "pass1 store"]
 print(prec, "clock ticks per wave (median / p10 / p90) over", dt.shape[0], "blocks x 8 waves; s_memtime ticks at 100 MHz => x ~21 shader cycles")
 for i, n in enumerate(names):
     v = dt[:, :, i].ravel()
     print(f"  {n:10s} {np.median(v):9.0f} {np.percentile(v,10):9.0f} {np.percentile(v,90):9.0f}")
-tot = (d[:, :, 5] - d[:, :, 0]).ravel()
+tot = (d[:, :, nst - 1] - d[:, :, 0]).ravel()
 print(f"  total      {np.median(tot):9.0f}")
 starts = d[:, 0, 0]; print("  block start spread (ticks):", int(starts.max() - starts.min()), " distinct rounds ~", np.unique(np.round((starts - starts.min()) / max(np.median(tot), 1))).size)

@@ -10,7 +10,9 @@ import ctypes as C
 import os
 from pathlib import Path
 
-_LIB_PATH = Path(__file__).resolve().parent / "liblightglue_amd.so"
+# LIGHTGLUE_AMD_LIB overrides the library file (A/B timing of two builds in one process tree); it must still be
+# a build of this package's csrc/ — there is no other implementation to fall back to.
+_LIB_PATH = Path(os.environ.get("LIGHTGLUE_AMD_LIB") or Path(__file__).resolve().parent / "liblightglue_amd.so")
 
 LG_PREC = {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3}
 LG_OK, LG_ERR_INVALID, LG_ERR_HIP, LG_ERR_STATE = 0, 1, 2, 3

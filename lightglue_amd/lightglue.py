@@ -142,11 +142,7 @@ class LightGlue(nn.Module):
             path = Path(__file__).parent / "weights" / f"{conf.weights}.pth"
             state_dict = torch.load(str(path), map_location="cpu")
         if state_dict:
-            # legacy key names (ref :427-434)
-            for i in range(L):
-                state_dict = {k.replace(f"self_attn.{i}", f"transformers.{i}.self_attn"): v for k, v in state_dict.items()}
-                state_dict = {k.replace(f"cross_attn.{i}", f"transformers.{i}.cross_attn"): v for k, v in state_dict.items()}
-            self.load_state_dict(state_dict, strict=False)
+            self.load_state_dict(self.rename_legacy_keys(state_dict, L), strict=False)
 
         self.static_lengths = None
         self._engine = None  # (handle, device_index, config signature)
@@ -155,6 +151,20 @@ class LightGlue(nn.Module):
         self.requires_grad_(False)
 
     # ------------------------------------------------------------------ weights
+    @staticmethod
+    def rename_legacy_keys(state_dict: dict, n_layers: int) -> dict:
+        """Released checkpoints name the blocks `self_attn.{i}.*` / `cross_attn.{i}.*`; the module tree uses
+        `transformers.{i}.self_attn.*` / `.cross_attn.*` (ref :427-434).  Already-renamed keys pass through."""
+        out = {}
+        for key, val in state_dict.items():
+            for i in range(n_layers):
+                for kind in ("self_attn", "cross_attn"):
+                    old = f"{kind}.{i}."
+                    if key.startswith(old):
+                        key = f"transformers.{i}.{kind}." + key[len(old):]
+            out[key] = val
+        return out
+
     def _find_pretrained(self, features: str, weights: str):
         """The reference downloads `{features}_lightglue.pth` (ref :416-421).  Look for the same file
         where torch.hub would have cached it or in ./weights; download only if the network allows."""

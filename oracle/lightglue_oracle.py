@@ -116,8 +116,11 @@ class _Ctx:
 
     def mm(self, a, b, where="lin"):
         """a @ b with optional operand rounding; accumulation in ``dtype``."""
-        r = _ROUNDERS[self.quant.get(where)]
-        a, b = r(a), r(b)
+        mode = self.quant.get(where, self.quant.get("lin"))   # lin_* tags fall back to "lin"
+        if isinstance(mode, tuple):   # (activation rounding, weight rounding) for asymmetric-operand studies
+            a, b = _ROUNDERS[mode[0]](a), _ROUNDERS[mode[1]](b)
+        else:
+            a, b = _ROUNDERS[mode](a), _ROUNDERS[mode](b)
         # BLAS needs a unit stride in one of the last two axes; the q/k/v views of the interleaved Wqkv
         # output (ref :166-167) have stride 3 and would fall back to numpy's slow generic loop
         if a.ndim >= 2 and a.strides[-1] != a.itemsize and a.strides[-2] != a.itemsize:
@@ -214,27 +217,27 @@ def attention(ctx: _Ctx, q, k, v):
 
 def _ffn(ctx: _Ctx, p: Dict[str, np.ndarray], prefix: str, x, msg, tr=None, tag=""):
     """ref :152-157 / :187-192 applied as x + ffn(cat[x,msg]) (ref :172, :228-229)."""
-    h = ctx.linear(np.concatenate([x, msg], -1), p[prefix + "ffn.0.weight"], p[prefix + "ffn.0.bias"])
+    h = ctx.linear(np.concatenate([x, msg], -1), p[prefix + "ffn.0.weight"], p[prefix + "ffn.0.bias"], "lin_ffn0")
     if tr is not None:
         tr[tag + "h1"] = h
     h = _layernorm(h, p[prefix + "ffn.1.weight"], p[prefix + "ffn.1.bias"])
     h = _gelu(h)
     if tr is not None:
         tr[tag + "g"] = h
-    return x + ctx.linear(h, p[prefix + "ffn.3.weight"], p[prefix + "ffn.3.bias"])
+    return x + ctx.linear(h, p[prefix + "ffn.3.weight"], p[prefix + "ffn.3.bias"], "lin_ffn3")
 
 
 def self_block(ctx: _Ctx, p, i: int, x, cos, sin, heads: int, tr=None, tag=""):
     """ref :159-172.  x [n,256].  ``tr`` (dict) receives the intermediates under ``tag``-prefixed keys."""
     pre = f"transformers.{i}.self_attn."
     n = x.shape[0]
-    qkv = ctx.linear(x, p[pre + "Wqkv.weight"], p[pre + "Wqkv.bias"])  # [n,768]
+    qkv = ctx.linear(x, p[pre + "Wqkv.weight"], p[pre + "Wqkv.bias"], "lin_qkv")  # [n,768]
     qkv = qkv.reshape(n, heads, -1, 3).transpose(1, 0, 2, 3)  # unflatten(-1,(H,-1,3)).transpose(1,2)
     q, k, v = qkv[..., 0], qkv[..., 1], qkv[..., 2]  # [H,n,64]
     q = apply_rotary(q, cos, sin)
     k = apply_rotary(k, cos, sin)
     context = attention(ctx, q, k, v)  # [H,n,64]
-    message = ctx.linear(context.transpose(1, 0, 2).reshape(n, -1), p[pre + "out_proj.weight"], p[pre + "out_proj.bias"])
+    message = ctx.linear(context.transpose(1, 0, 2).reshape(n, -1), p[pre + "out_proj.weight"], p[pre + "out_proj.bias"], "lin_out")
     if tr is not None:
         tr[tag + "q"], tr[tag + "k"], tr[tag + "v"] = q, k, v
         tr[tag + "ctx"], tr[tag + "msg"] = context.transpose(1, 0, 2).reshape(n, -1), message
@@ -246,10 +249,10 @@ def cross_block(ctx: _Ctx, p, i: int, x0, x1, heads: int, tr=None, tag=""):
     pre = f"transformers.{i}.cross_attn."
     def heads_of(t):
         return t.reshape(t.shape[0], heads, -1).transpose(1, 0, 2)
-    qk0 = heads_of(ctx.linear(x0, p[pre + "to_qk.weight"], p[pre + "to_qk.bias"]))
-    qk1 = heads_of(ctx.linear(x1, p[pre + "to_qk.weight"], p[pre + "to_qk.bias"]))
-    v0 = heads_of(ctx.linear(x0, p[pre + "to_v.weight"], p[pre + "to_v.bias"]))
-    v1 = heads_of(ctx.linear(x1, p[pre + "to_v.weight"], p[pre + "to_v.bias"]))
+    qk0 = heads_of(ctx.linear(x0, p[pre + "to_qk.weight"], p[pre + "to_qk.bias"], "lin_qkv"))
+    qk1 = heads_of(ctx.linear(x1, p[pre + "to_qk.weight"], p[pre + "to_qk.bias"], "lin_qkv"))
+    v0 = heads_of(ctx.linear(x0, p[pre + "to_v.weight"], p[pre + "to_v.bias"], "lin_qkv"))
+    v1 = heads_of(ctx.linear(x1, p[pre + "to_v.weight"], p[pre + "to_v.bias"], "lin_qkv"))
     if tr is not None:
         tr[tag + "qk0"], tr[tag + "qk1"], tr[tag + "v0"], tr[tag + "v1"] = qk0, qk1, v0, v1
     if x0.shape[0] == 0 or x1.shape[0] == 0:
@@ -267,8 +270,8 @@ def cross_block(ctx: _Ctx, p, i: int, x0, x1, heads: int, tr=None, tag=""):
         return t.transpose(1, 0, 2).reshape(t.shape[1], -1)
     if tr is not None:
         tr[tag + "ctx0"], tr[tag + "ctx1"] = merge(m0), merge(m1)
-    m0 = ctx.linear(merge(m0), p[pre + "to_out.weight"], p[pre + "to_out.bias"])
-    m1 = ctx.linear(merge(m1), p[pre + "to_out.weight"], p[pre + "to_out.bias"])
+    m0 = ctx.linear(merge(m0), p[pre + "to_out.weight"], p[pre + "to_out.bias"], "lin_out")
+    m1 = ctx.linear(merge(m1), p[pre + "to_out.weight"], p[pre + "to_out.bias"], "lin_out")
     if tr is not None:
         tr[tag + "msg0"], tr[tag + "msg1"] = m0, m1
     return (_ffn(ctx, p, pre, x0, m0, tr, tag + "i0_"), _ffn(ctx, p, pre, x1, m1, tr, tag + "i1_"))

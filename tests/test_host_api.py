@@ -104,3 +104,21 @@ def test_utils_glue_mirrors_reference():
     assert d["a"].shape == (3,) and d["b"].shape == (2,) and d["c"] == 4
     moved = batch_to_device({"x": {"y": torch.zeros(2)}, "s": "name"}, "cpu")
     assert moved["s"] == "name" and moved["x"]["y"].device.type == "cpu"
+
+
+def test_legacy_checkpoint_key_rename():
+    """ref :427-434: released .pth files use self_attn.{i}/cross_attn.{i}; they must load unchanged."""
+    m = LightGlue(features=None, n_layers=3)
+    sd = m.state_dict()
+    legacy = {}
+    for k, v in sd.items():
+        for i in range(3):
+            k = k.replace(f"transformers.{i}.self_attn", f"self_attn.{i}").replace(f"transformers.{i}.cross_attn", f"cross_attn.{i}")
+        legacy[k] = v + 1.0 if v.dtype.is_floating_point else v
+    assert any(k.startswith("self_attn.2.") for k in legacy) and not any(k.startswith("transformers.") for k in legacy)
+    renamed = LightGlue.rename_legacy_keys(legacy, 3)
+    assert set(renamed) == set(sd)
+    res = m.load_state_dict(renamed, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert torch.equal(m.state_dict()["transformers.2.cross_attn.to_qk.weight"], legacy["cross_attn.2.to_qk.weight"])
+    assert LightGlue.rename_legacy_keys(renamed, 3).keys() == renamed.keys()   # idempotent

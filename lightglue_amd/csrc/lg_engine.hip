@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -93,7 +94,7 @@ struct lg_engine {
     size_t tail_cat_layer_bytes = 0, tail_2_layer_bytes = 0;
     char *w_sqkv_p = nullptr, *w_cqkv_p = nullptr;   // fragment-packed projection weights (lg_proj.hip)
     size_t sqkv_layer_bytes = 0, cqkv_layer_bytes = 0;
-    int fused_tail = 1, fused_proj = 1;
+    int fused_tail = 1, fused_proj = 1, tail_variant = 0;   // tail_variant: 0 = 8-wave kernel, 1 = 4-wave kernel
     int tail_timing = 0; long long* TAILDBG = nullptr;
     // ---- workspace
     void* ws = nullptr; size_t ws_bytes = 0;
@@ -305,6 +306,7 @@ int lg_engine_create(const lg_config* cfg, lg_engine** out) {
     if (ap < 0) ap = cfg->precision == LG_PREC_BF16X3 ? PREC_F16 : cfg->precision;
     if (ap != PREC_F32 && ap != PREC_BF16 && ap != PREC_F16) { delete e; return fail(LG_ERR_INVALID, "bad attn_precision"); }
     e->attn_prec = ap;
+    if (const char* tv = std::getenv("LG_TAIL_VARIANT")) e->tail_variant = std::atoi(tv);   // A/B switch for experiments
     *out = e;
     return LG_OK;
 }
@@ -485,6 +487,7 @@ int lg_engine_reserve(lg_engine* e, int32_t max_batch, int32_t max_n0, int32_t m
 int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
     if (!e || !key) return fail(LG_ERR_INVALID, "null argument");
     if (std::strcmp(key, "fused_tail") == 0) { e->fused_tail = value != 0; return LG_OK; }
+    if (std::strcmp(key, "tail_variant") == 0) { e->tail_variant = value; return LG_OK; }
     if (std::strcmp(key, "fused_proj") == 0) { e->fused_proj = value != 0; return LG_OK; }
     if (std::strcmp(key, "tail_timing") == 0) { e->tail_timing = value; return LG_OK; }   // 1: tail kernel, 2: self projection
     return fail(LG_ERR_INVALID, std::string("unknown option '") + key + "'");
@@ -619,7 +622,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 ta.b2 = (blk ? e->b_cf2 : e->b_sf2) + (size_t)i * D;
                 ta.dbg = e->tail_timing == 1 ? e->TAILDBG : nullptr;
                 TRY(prof_begin(e, PC_TAIL, s));
-                HIPCHK(launch_tail(prec, ta, s));
+                HIPCHK(e->tail_variant == 1 ? launch_tail4(prec, ta, s) : launch_tail(prec, ta, s));
                 TRY(prof_end(e, s));
                 STEP_DONE(); STEP_DONE(); STEP_DONE(); STEP_DONE();
                 continue;

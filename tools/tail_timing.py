@@ -16,7 +16,7 @@ model(data); model.set_option("tail_timing", which); model(data); torch.cuda.syn
 nst = 6 if which == 1 else 8
 d = model.debug_read("TAILDBG", np.int64).reshape(-1, 8, 8)[:, :, :nst]
 dt = np.diff(d, axis=2).astype(np.float64)
-names = ["phaseA", "LN+GELU", "g->LDS", "phaseB", "epilogue"] if which == 1 else ["A tile -> LDS", "pass0 MFMA", "pass0 bias/rope/stage", "pass0 store", "pass1 MFMA", "pass1 stage", "pass1 store"]
+names = ["phaseA", "LN", "GELU0", "phaseB+GELU", "epilogue"] if which == 1 else ["A tile -> LDS", "pass0 MFMA", "pass0 bias/rope/stage", "pass0 store", "pass1 MFMA", "pass1 stage", "pass1 store"]
 print(prec, "clock ticks per wave (median / p10 / p90) over", dt.shape[0], "blocks x 8 waves; s_memtime ticks at 100 MHz => x ~21 shader cycles")
 for i, n in enumerate(names):
     v = dt[:, :, i].ravel()

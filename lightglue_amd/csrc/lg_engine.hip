@@ -94,7 +94,7 @@ struct lg_engine {
     size_t tail_cat_layer_bytes = 0, tail_2_layer_bytes = 0;
     char *w_sqkv_p = nullptr, *w_cqkv_p = nullptr;   // fragment-packed projection weights (lg_proj.hip)
     size_t sqkv_layer_bytes = 0, cqkv_layer_bytes = 0;
-    int fused_tail = 1, fused_proj = 1, tail_variant = 0;   // tail_variant: 0 = 8-wave kernel, 1 = 4-wave kernel
+    int fused_tail = 1, fused_proj = 1, tail_variant = 0;   // 0 = lg_tail.hip (64 rows, LDS-resident), 1 = 4 waves x 64 rows, 2 = 8 waves x 128 rows
     int tail_timing = 0; long long* TAILDBG = nullptr;
     // ---- workspace
     void* ws = nullptr; size_t ws_bytes = 0;
@@ -622,7 +622,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 ta.b2 = (blk ? e->b_cf2 : e->b_sf2) + (size_t)i * D;
                 ta.dbg = e->tail_timing == 1 ? e->TAILDBG : nullptr;
                 TRY(prof_begin(e, PC_TAIL, s));
-                HIPCHK(e->tail_variant == 1 ? launch_tail4(prec, ta, s) : launch_tail(prec, ta, s));
+                HIPCHK(e->tail_variant == 1 ? launch_tail4(prec, ta, s) : e->tail_variant == 2 ? launch_tail128(prec, ta, s) : launch_tail(prec, ta, s));
                 TRY(prof_end(e, s));
                 STEP_DONE(); STEP_DONE(); STEP_DONE(); STEP_DONE();
                 continue;

@@ -54,7 +54,8 @@ struct TailArgs {
     long long* dbg;                          // profiling tap: [blocks][8 waves][8] shader-clock stamps, or nullptr
 };
 hipError_t launch_tail(int prec, const TailArgs& a, hipStream_t s);    // 8 waves, one workgroup per CU (lg_tail.hip)
-hipError_t launch_tail4(int prec, const TailArgs& a, hipStream_t s);   // 4 waves, two workgroups per CU (lg_tail4.hip)
+hipError_t launch_tail4(int prec, const TailArgs& a, hipStream_t s);   // 4 waves x 64 rows, two workgroups per CU (lg_tail4.hip)
+hipError_t launch_tail128(int prec, const TailArgs& a, hipStream_t s); // 8 waves x 128 rows: half the weight stream per row (lg_tail4.hip)
 
 // ---------------------------------------------------------------- attention input projections (lg_proj.hip)
 // q/k/v (self, rotary on q,k) or qk/v (cross) from the residual stream; weights fragment-packed like TailArgs

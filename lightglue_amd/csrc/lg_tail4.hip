@@ -1,21 +1,20 @@
-// lightglue_amd — fused block tail, 4-wave variant:  x <- x + ffn(cat[x, out_proj(ctx)])   (see lg_tail.hip for the
-// algebra, reference lines and the weight packing; this file only changes the workgroup decomposition).
+// lightglue_amd — fused block tail, streaming variants:  x <- x + ffn(cat[x, out_proj(ctx)])   (see lg_tail.hip for
+// the algebra, the reference lines and the weight packing; this file changes the workgroup decomposition only).
 //
-// lg_tail.hip runs ONE 8-wave workgroup per CU (133 KB of LDS): its MFMA phases and its VALU phases (LayerNorm,
-// GELU, split + transposition of g) alternate in lock-step, so the matrix pipe idles ~60 % of the time.
-// Here a workgroup is 4 waves (one per SIMD) x 64 rows and needs < 70 KB of LDS, so TWO workgroups share a CU and
-// drift apart: while one is in a VALU phase the other one's MFMAs own the matrix pipe.
-//   * phase A streams the [x ; ctx] tile through a double-buffered 2 x 16 KB LDS stage (one barrier per 64-wide
-//     K stage) instead of keeping it resident;
-//   * wave w owns the hidden n-tiles {w + 4j, j < 8} (128 accumulator registers); weight fragments are fetched in
-//     half-chunks (4 n-tiles) on a two-deep register ring so that one half is in flight while the other is multiplied;
-//   * phase B runs in 8 steps of 64 hidden units: GELU + split + transposition of ONE n-tile per wave into a
-//     two-slot LDS ring, barrier, 2 k-chunks of MFMAs.
+// Ablations of lg_tail.hip showed that the fused tail is NOT bound by the matrix cores but by the per-CU
+// vector-memory path that streams the weight fragments L2 -> VGPR (~24 B/clk/CU): with 64 rows per workgroup every
+// weight byte feeds too few MACs.  tailx_kernel<PREC, NW, MT> keeps the structure (activations through LDS, weight
+// fragments pre-packed in MFMA order straight from L2, waves split the output columns) but
+//   * streams the [x ; ctx] tile through a double-buffered LDS stage (one barrier per 64-wide K stage) instead of
+//     keeping it resident, and runs GELU + ffn.3 in steps over a two-slot LDS ring of g, so LDS no longer caps the tile;
+//   * <NW = 8, MT = 8>: 128 rows per workgroup — every weight fragment is reused by 8 row tiles instead of 4,
+//     i.e. HALF the weight stream per keypoint (variant 2, default);
+//   * <NW = 4, MT = 4>: 64 rows, 4 waves, < 70 KB LDS — two unsynchronised workgroups per CU (variant 1; measured
+//     +-1 % vs lg_tail.hip: overlapping MFMA and VALU phases does not help a load-bound kernel).
+// Wave w owns the hidden n-tiles {w + NW*j} and the output n-tiles {w + NW*n}.
 #include "lg_kernels.h"
 
 namespace lg {
-
-constexpr int QBM = 64, QTHREADS = 256;
 
 template <int PREC> struct QT;
 template <> struct QT<PREC_F32> { typedef TagF32 Tag; static constexpr int NPART = 1; };
@@ -44,44 +43,51 @@ __device__ __forceinline__ f32x2 gelu4_fast2(f32x2 u) {   // same branch-free GE
     return half_u + half_u * sgn;
 }
 
-template <int PREC>
-__device__ __forceinline__ void q_mma(f32x4& acc, const u32x4* a, const u32x4* b) {
-    typedef typename QT<PREC>::Tag Tag;
-    if constexpr (QT<PREC>::NPART == 2) {
-        mma_chunk<Tag>(acc, a[1], b[0]);
-        mma_chunk<Tag>(acc, a[0], b[1]);
-    }
-    mma_chunk<Tag>(acc, a[0], b[0]);
-}
-// product-major over N accumulators of one 16-row tile: no back-to-back dependent MFMAs
-template <int PREC, int N, int STRIDE>
+// N accumulators of one 16-row tile against one A fragment; product-major (hi*lo terms first)
+template <int PREC, int N>
 __device__ __forceinline__ void q_mma_row(f32x4* acc, const u32x4* a, const u32x4 (*b)[QT<PREC>::NPART]) {
     typedef typename QT<PREC>::Tag Tag;
     constexpr int NP = QT<PREC>::NPART;
 #pragma unroll
     for (int pr = 0; pr < (NP == 2 ? 3 : 1); ++pr)
 #pragma unroll
-        for (int j = 0; j < N; ++j) mma_chunk<Tag>(acc[j * STRIDE], a[NP == 2 && pr == 0 ? 1 : 0], b[j][NP == 2 && pr == 1 ? 1 : 0]);
+        for (int j = 0; j < N; ++j) mma_chunk<Tag>(acc[j], a[NP == 2 && pr == 0 ? 1 : 0], b[j][NP == 2 && pr == 1 ? 1 : 0]);
 }
 
-template <int PREC>
-__global__ __launch_bounds__(QTHREADS, 2) void tail4_kernel(TailArgs a) {
+template <int PREC, int NW, int MT> struct TX {
     typedef typename QT<PREC>::Tag Tag;
-    constexpr int EPC = Tag::EPC, NPART = QT<PREC>::NPART;
-    constexpr int KE = 8 * EPC;               // K elements per 128-byte stage row: 64 (16-bit) / 32 (f32)
-    constexpr int STAGES = 512 / KE;          // 8 / 16
-    constexpr int NKC = 2 * STAGES;           // 16-byte k-chunks per row: 16 / 32
-    constexpr int NV = EPC / 4;
-    constexpr int TILE = QBM * 128;           // one plane of one stage tile (8 KB)
-    constexpr int STEP_TILES = 64 / KE;       // stage tiles per 64 hidden units: 1 / 2
-    constexpr int PLANE = STEP_TILES * TILE;  // one plane of one ring slot / staging buffer
-    constexpr int SLOT = NPART * PLANE;       // ring slot == staging buffer size (phase A stages 64 K elements at once for f32 too)
-    constexpr int CPS = 64 / (4 * EPC);       // k-chunks per 64 hidden units: 2 / 4
-    constexpr int OLD = 260;                  // padded fp32 output row stride
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = reinterpret_cast<float*>(smem + (2 * SLOT > QBM * OLD * 4 ? 2 * SLOT : QBM * OLD * 4));
+    static constexpr int EPC = Tag::EPC, NPART = QT<PREC>::NPART;
+    static constexpr int ROWS = MT * 16, THREADS = NW * 64;
+    static constexpr int KE = 8 * EPC;                    // K elements per 128-byte row of a stage tile (64 / 32)
+    static constexpr int NKC = 512 / (4 * EPC);           // 16-byte k-chunks per row of K = 512 (16 / 32)
+    static constexpr int TILE = ROWS * 128;               // one plane of one stage tile
+    static constexpr int STG_TILES = 64 / KE;             // phase A stages 64 K elements at a time (1 / 2 tiles)
+    static constexpr int STG_PLANE = STG_TILES * TILE, STG_BUF = NPART * STG_PLANE;
+    static constexpr int STEP_H = NW * 16;                // hidden units per phase-B step (one n-tile per wave)
+    static constexpr int NSTEP = 512 / STEP_H;
+    static constexpr int RING_TILES = STEP_H / KE, RING_PLANE = RING_TILES * TILE, SLOT = NPART * RING_PLANE;
+    static constexpr int CPSS = 64 / (4 * EPC);           // k-chunks per phase-A super-stage (2 / 4)
+    static constexpr int CPST = STEP_H / (4 * EPC);       // k-chunks per phase-B step
+    static constexpr int OLD = 260;                       // padded fp32 output row stride
+    static constexpr int OUT_BYTES = ROWS * OLD * 4;
+    static constexpr int R0 = 2 * STG_BUF > 2 * SLOT ? 2 * STG_BUF : 2 * SLOT;
+    static constexpr int REGION = R0 > OUT_BYTES ? R0 : OUT_BYTES;
+    static constexpr int LDS = REGION + NW * ROWS * 4;
+    static constexpr int NTA = 32 / NW, NGA = NTA / 4;    // phase-A n-tiles per wave, groups of 4 per k-chunk
+    static constexpr int NTB = 16 / NW, NGB = NTB / 2;    // phase-B n-tiles per wave, groups of 2 per k-chunk
+    static constexpr int CPT = STG_TILES * ROWS * 8 / THREADS;   // staged 16-byte chunks per thread per super-stage
+    static constexpr bool B2_DOUBLE = !(NPART == 2 && NW == 4);  // (4 waves, split): registers allow one ffn.3 group only
+};
 
-    const TileLoc t = locate_tile(a.rs, blockIdx.x, QBM);
+template <int PREC, int NW, int MT>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void tailx_kernel(TailArgs a) {
+    typedef TX<PREC, NW, MT> C;
+    typedef typename C::Tag Tag;
+    constexpr int EPC = C::EPC, NPART = C::NPART, NV = EPC / 4, KE = C::KE, NKC = C::NKC, TILE = C::TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem + C::REGION);
+
+    const TileLoc t = locate_tile(a.rs, blockIdx.x, C::ROWS);
     if (t.r0 >= a.rs.len[t.seg]) return;
     if (a.rs.active && !a.rs.active[t.pair]) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
@@ -95,32 +101,31 @@ __global__ __launch_bounds__(QTHREADS, 2) void tail4_kernel(TailArgs a) {
     };
 
     // ------------------------------------------------------------------ phase A: h = [x ; ctx] Wcat^T
-    f32x4 acc[4][8];
+    f32x4 acc[MT][C::NTA];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < C::NTA; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // staging: "super-stage" S = 64 K elements = STEP_TILES stage tiles; thread -> 2 x STEP_TILES chunks
-    f32x4 stg[2 * STEP_TILES][NV];
+    f32x4 stg[C::CPT][NV];
     auto load_stage = [&](int S) {
         const int k0 = S * 64;
         const float* src0 = (k0 < 256 ? a.X : a.CTX) + (long long)t.grow0 * 256 + (k0 & 255);
 #pragma unroll
-        for (int i = 0; i < 2 * STEP_TILES; ++i) {
-            const int c = tid + QTHREADS * i;                    // chunk id within the super-stage
-            const int tl = c / 512, cc = c % 512, row = cc >> 3, slot = cc & 7;
+        for (int i = 0; i < C::CPT; ++i) {
+            const int c = tid + C::THREADS * i;
+            const int tl = c / (C::ROWS * 8), cc = c % (C::ROWS * 8), row = cc >> 3, slot = cc & 7;
             const float* p = src0 + (long long)row * 256 + tl * KE + slot * EPC;
 #pragma unroll
             for (int j = 0; j < NV; ++j) stg[i][j] = *reinterpret_cast<const f32x4*>(p + 4 * j);
         }
     };
     auto store_stage = [&](int S) {
-        char* buf = smem + (S & 1) * SLOT;
+        char* buf = smem + (S & 1) * C::STG_BUF;
 #pragma unroll
-        for (int i = 0; i < 2 * STEP_TILES; ++i) {
-            const int c = tid + QTHREADS * i;
-            const int tl = c / 512, cc = c % 512, row = cc >> 3, slot = cc & 7;
+        for (int i = 0; i < C::CPT; ++i) {
+            const int c = tid + C::THREADS * i;
+            const int tl = c / (C::ROWS * 8), cc = c % (C::ROWS * 8), row = cc >> 3, slot = cc & 7;
             char* tile = buf + tl * TILE;
             const int off = lds_off<128>(row, slot);
             if constexpr (PREC == PREC_F32) {
@@ -129,242 +134,211 @@ __global__ __launch_bounds__(QTHREADS, 2) void tail4_kernel(TailArgs a) {
                 u32x4 hi, lo;
                 split8_bf16(stg[i][0], stg[i][1], hi, lo);
                 *reinterpret_cast<u32x4*>(tile + off) = hi;
-                *reinterpret_cast<u32x4*>(tile + PLANE + off) = lo;
+                *reinterpret_cast<u32x4*>(tile + C::STG_PLANE + off) = lo;
             } else {
                 *reinterpret_cast<u32x4*>(tile + off) = pack8<Tag>(stg[i][0], stg[i][1]);
             }
         }
     };
-    // weight half-chunks: half hb of k-chunk kc = n-tiles j = 4*hb .. 4*hb+3 of this wave (global n-tile w + 4j)
+    // weight groups: group ga of k-chunk kc = this wave's n-tiles j = 4*ga .. 4*ga+3 (global n-tile w + NW*j); two register
+    // buffers: the next group is in flight while the current one is multiplied.  No branch around a prefetch (clamped
+    // instead) and sched_barrier(0) around it — see lg_tail.hip.
     u32x4 bh[2][4][NPART];
-    auto load_bh = [&](u32x4 (&dst)[4][NPART], int kc, int hb) {
+    auto load_bh = [&](u32x4 (&dst)[4][NPART], int kc, int ga) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int p = 0; p < NPART; ++p) dst[j][p] = wfrag(a.Wcat, p, 512LL * 512, w + 4 * (4 * hb + j), kc);
+            for (int p = 0; p < NPART; ++p) dst[j][p] = wfrag(a.Wcat, p, 512LL * 512, w + NW * (4 * ga + j), kc);
     };
     load_stage(0);
     load_bh(bh[0], 0, 0);
-    constexpr int NSS = 512 / 64;   // super-stages
 #pragma unroll 1
-    for (int S = 0; S < NSS; ++S) {
+    for (int S = 0; S < 8; ++S) {
         store_stage(S);
         __syncthreads();
-        load_stage(S + 1 < NSS ? S + 1 : S);   // clamped, never branched (hipcc's vmcnt counting)
+        load_stage(S + 1 < 8 ? S + 1 : S);
         __builtin_amdgcn_sched_barrier(0);
-        const char* buf = smem + (S & 1) * SLOT;
+        const char* buf = smem + (S & 1) * C::STG_BUF;
 #pragma unroll
-        for (int i = 0; i < CPS; ++i) {
-            const int kc = S * CPS + i;
+        for (int i = 0; i < C::CPSS; ++i) {
+            const int kc = S * C::CPSS + i;
             const char* tile = buf + (i >> 1) * TILE;
-            // A fragments are (re)read per 16-row tile right before use: 8 live registers instead of 32 — the
-            // accumulators (128) + the weight ring (64) leave no room for more under the 256-register cap
-            auto afrag = [&](u32x4 (&af)[NPART], int mt) {
+            auto afrag = [&](u32x4 (&af)[NPART], int mt) {   // (re)read per 16-row tile: 8 live registers instead of 8*MT
 #pragma unroll
                 for (int p = 0; p < NPART; ++p)
-                    af[p] = *reinterpret_cast<const u32x4*>(tile + p * PLANE + lds_off<128>(mt * 16 + lr, (i & 1) * 4 + g));
+                    af[p] = *reinterpret_cast<const u32x4*>(tile + p * C::STG_PLANE + lds_off<128>(mt * 16 + lr, (i & 1) * 4 + g));
             };
-            load_bh(bh[1], kc, 1);
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                u32x4 af[NPART];
-                afrag(af, mt);
+            for (int ga = 0; ga < C::NGA; ++ga) {
+                const int cur = C::NGA == 2 ? ga : (i & 1);                 // compile-time after unrolling (CPSS is even)
+                const bool last = ga + 1 == C::NGA;
+                load_bh(bh[cur ^ 1], last ? (kc + 1 < NKC ? kc + 1 : kc) : kc, last ? 0 : ga + 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 1; ++j) q_mma_row<PREC, 4, 1>(&acc[mt][0], af, bh[0]);
+                for (int mt = 0; mt < MT; ++mt) {
+                    u32x4 af[NPART];
+                    afrag(af, mt);
+                    q_mma_row<PREC, 4>(&acc[mt][4 * ga], af, bh[cur]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            load_bh(bh[0], kc + 1 < NKC ? kc + 1 : kc, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                u32x4 af[NPART];
-                afrag(af, mt);
-#pragma unroll
-                for (int j = 0; j < 1; ++j) q_mma_row<PREC, 4, 1>(&acc[mt][4], af, bh[1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
     stamp(1);
-    // ------------------------------------------------------------------ bias + LayerNorm(512) statistics
+    // ------------------------------------------------------------------ bias + LayerNorm(512)
     {
-        float part[4][4];
+        float part[MT][4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[mt][r] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float bv = a.bcat[(w + 4 * j) * 16 + lr];
+        for (int j = 0; j < C::NTA; ++j) {
+            const float bv = a.bcat[(w + NW * j) * 16 + lr];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { acc[mt][j][r] += bv; part[mt][r] += acc[mt][j][r]; }
         }
-        auto block_row_sum = [&](float (&p)[4][4]) {
+        auto block_row_sum = [&](float (&p)[MT][4]) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) p[mt][r] = row16_sum(p[mt][r]);
             __syncthreads();
             if (lr == 0) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) red[w * QBM + mt * 16 + g * 4 + r] = p[mt][r];
+                    for (int r = 0; r < 4; ++r) red[w * C::ROWS + mt * 16 + g * 4 + r] = p[mt][r];
             }
             __syncthreads();
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(red + mt * 16 + g * 4);
 #pragma unroll
-                for (int ww = 1; ww < 4; ++ww) v += *reinterpret_cast<const f32x4*>(red + ww * QBM + mt * 16 + g * 4);
+                for (int ww = 1; ww < NW; ++ww) v += *reinterpret_cast<const f32x4*>(red + ww * C::ROWS + mt * 16 + g * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) p[mt][r] = v[r];
+                __builtin_amdgcn_sched_barrier(0);   // bound the live range: MT*NW 16-byte reads hoisted together would spill
             }
         };
         block_row_sum(part);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float mean = part[mt][r] * (1.f / 512.f);
                 float sq = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float d = acc[mt][j][r] - mean; acc[mt][j][r] = d; sq += d * d; }
+                for (int j = 0; j < C::NTA; ++j) { const float d = acc[mt][j][r] - mean; acc[mt][j][r] = d; sq += d * d; }
                 part[mt][r] = sq;
             }
         block_row_sum(part);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part[mt][r] = __builtin_amdgcn_rsqf(part[mt][r] * (1.f / 512.f) + 1e-5f);   // rstd
-        // normalise + affine now (pre-GELU values stay in the accumulators until their step)
+            for (int r = 0; r < 4; ++r) part[mt][r] = __builtin_amdgcn_rsqf(part[mt][r] * (1.f / 512.f) + 1e-5f);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int col = (w + 4 * j) * 16 + lr;
+        for (int j = 0; j < C::NTA; ++j) {   // normalise + affine now; GELU happens at the tile's step
+            const int col = (w + NW * j) * 16 + lr;
             const float gm = a.gamma[col], bt = a.beta[col];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[mt][j][r] = acc[mt][j][r] * part[mt][r] * gm + bt;
         }
     }
     stamp(2);
-    // ------------------------------------------------------------------ phase B: 8 steps of 64 hidden units
-    // step j: this wave's n-tile j = hidden units [(w+4j)*16, +16) = columns [16w, 16w+16) of the step's 64
+    // ------------------------------------------------------------------ phase B: NSTEP steps of STEP_H hidden units
+    // step j: this wave's n-tile j = hidden units [(w + NW*j)*16, +16) = columns [16w, 16w+16) of the step
     auto gelu_store = [&](int j) {
-        char* slot = smem + (j & 1) * SLOT;
+        char* slot = smem + (j & 1) * C::SLOT;
+        const int hc = w * 16;                         // first column of this wave inside the step
+        char* tile0 = slot + (hc / KE) * TILE;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             const f32x2 v01 = gelu4_fast2(f32x2{acc[mt][j][0], acc[mt][j][1]});
             const f32x2 v23 = gelu4_fast2(f32x2{acc[mt][j][2], acc[mt][j][3]});
             const float gv[4] = {v01[0], v01[1], v23[0], v23[1]};
             if constexpr (EPC == 8) {
 #pragma unroll
-                for (int rp = 0; rp < 4; rp += 2) {
+                for (int rp = 0; rp < 4; rp += 2) {   // even lanes write row rp, odd lanes row rp+1, as (even col, odd col) pairs
                     const bool odd = lr & 1;
                     const float mine = odd ? gv[rp + 1] : gv[rp];
                     const float give = odd ? gv[rp] : gv[rp + 1];
                     const float got = dpp_xor1(give);
                     const float c0 = odd ? got : mine, c1 = odd ? mine : got;
                     const int row = mt * 16 + g * 4 + rp + (odd ? 1 : 0);
-                    const int col = w * 16 + (lr & ~1);
+                    const int col = (hc % KE) + (lr & ~1);
                     const int off = lds_off<128>(row, col >> 3) + (col & 7) * 2;
                     if constexpr (PREC == PREC_BF16X3) {
                         const float h0 = bf16_round(c0), h1 = bf16_round(c1);
-                        *reinterpret_cast<uint32_t*>(slot + off) = pack2_bf16(h0, h1);
-                        *reinterpret_cast<uint32_t*>(slot + PLANE + off) = pack2_bf16(c0 - h0, c1 - h1);
+                        *reinterpret_cast<uint32_t*>(tile0 + off) = pack2_bf16(h0, h1);
+                        *reinterpret_cast<uint32_t*>(tile0 + C::RING_PLANE + off) = pack2_bf16(c0 - h0, c1 - h1);
                     } else {
-                        *reinterpret_cast<uint32_t*>(slot + off) = pack2<Tag>(c0, c1);
+                        *reinterpret_cast<uint32_t*>(tile0 + off) = pack2<Tag>(c0, c1);
                     }
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int c = w * 16 + lr, row = mt * 16 + g * 4 + r;     // 0..63 within the step; f32 tile = 32 columns
-                    *reinterpret_cast<float*>(slot + (c >> 5) * TILE + lds_off<128>(row, (c & 31) >> 2) + (c & 3) * 4) = gv[r];
+                    const int c = (hc % KE) + lr, row = mt * 16 + g * 4 + r;
+                    *reinterpret_cast<float*>(tile0 + lds_off<128>(row, c >> 2) + (c & 3) * 4) = gv[r];
                 }
             }
         }
     };
-    f32x4 acc2[4][4];
+    f32x4 acc2[MT][C::NTB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    u32x4 b2h[NPART == 2 ? 1 : 2][2][NPART];   // half-chunks of ffn.3 fragments: out n-tiles w + 4*(2*hb + {0,1})
-    auto load_b2h = [&](u32x4 (&dst)[2][NPART], int kc, int hb) {
+        for (int j = 0; j < C::NTB; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 b2h[C::B2_DOUBLE ? 2 : 1][2][NPART];   // groups of 2 out n-tiles: global n-tile w + NW*(2*gb + {0,1})
+    auto load_b2h = [&](u32x4 (&dst)[2][NPART], int kc, int gb) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int p = 0; p < NPART; ++p) dst[j][p] = wfrag(a.W2, p, 256LL * 512, w + 4 * (2 * hb + j), kc);
+            for (int p = 0; p < NPART; ++p) dst[j][p] = wfrag(a.W2, p, 256LL * 512, w + NW * (2 * gb + j), kc);
     };
-    load_b2h(b2h[0], 0, 0);
-    // the barriers of block_row_sum ordered every wave past phase A: staging buffers are dead, the ring may reuse them
+    if constexpr (C::B2_DOUBLE) load_b2h(b2h[0], 0, 0);
+    // the barriers of block_row_sum ordered every wave past phase A: the staging buffers are dead, the ring may reuse them
     gelu_store(0);
     __syncthreads();
     stamp(3);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const char* slot = smem + (j & 1) * SLOT;
+    for (int j = 0; j < C::NSTEP; ++j) {
+        const char* slot = smem + (j & 1) * C::SLOT;
 #pragma unroll
-        for (int i = 0; i < CPS; ++i) {
-            const int kc = j * CPS + i;
+        for (int i = 0; i < C::CPST; ++i) {
+            const int kc = j * C::CPST + i;
             const char* tile = slot + (i >> 1) * TILE;
             auto afrag = [&](u32x4 (&af)[NPART], int mt) {
 #pragma unroll
                 for (int p = 0; p < NPART; ++p)
-                    af[p] = *reinterpret_cast<const u32x4*>(tile + p * PLANE + lds_off<128>(mt * 16 + lr, (i & 1) * 4 + g));
+                    af[p] = *reinterpret_cast<const u32x4*>(tile + p * C::RING_PLANE + lds_off<128>(mt * 16 + lr, (i & 1) * 4 + g));
             };
-            if constexpr (NPART == 2) {
-                // split bf16: accumulators of both GEMMs (<= 112 + 64) leave room for ONE half-chunk of weights: no
-                // register prefetch here — the co-resident workgroup's MFMAs cover the L2 latency
-                if (i > 0 || j > 0) load_b2h(b2h[0], kc, 0);
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    u32x4 af[NPART];
-                    afrag(af, mt);
-#pragma unroll
-                    for (int n = 0; n < 1; ++n) q_mma_row<PREC, 2, 1>(&acc2[mt][0], af, b2h[0]);
+            for (int gb = 0; gb < C::NGB; ++gb) {
+                int cur = 0;
+                if constexpr (C::B2_DOUBLE) {
+                    cur = C::NGB == 2 ? gb : (i & 1);                       // compile-time after unrolling (CPST is even)
+                    const bool last = gb + 1 == C::NGB;
+                    load_b2h(b2h[cur ^ 1], last ? (kc + 1 < NKC ? kc + 1 : kc) : kc, last ? 0 : gb + 1);
+                } else {
+                    load_b2h(b2h[0], kc, gb);   // no register prefetch: the co-resident workgroup covers the L2 latency
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                load_b2h(b2h[0], kc, 1);
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     u32x4 af[NPART];
                     afrag(af, mt);
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) q_mma<PREC>(acc2[mt][2 + n], af, b2h[0][n]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-                load_b2h(b2h[1], kc, 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    u32x4 af[NPART];
-                    afrag(af, mt);
-#pragma unroll
-                    for (int n = 0; n < 1; ++n) q_mma_row<PREC, 2, 1>(&acc2[mt][0], af, b2h[0]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                load_b2h(b2h[0], kc + 1 < NKC ? kc + 1 : kc, 0);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    u32x4 af[NPART];
-                    afrag(af, mt);
-#pragma unroll
-                    for (int n = 0; n < 1; ++n) q_mma_row<PREC, 2, 1>(&acc2[mt][2], af, b2h[1]);
+                    q_mma_row<PREC, 2>(&acc2[mt][2 * gb], af, b2h[cur]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (j < 7) {
+        if (j + 1 < C::NSTEP) {
             gelu_store(j + 1);     // other ring slot: every wave left it at the previous barrier
             __syncthreads();
         }
@@ -372,30 +346,31 @@ __global__ __launch_bounds__(QTHREADS, 2) void tail4_kernel(TailArgs a) {
     stamp(4);
     // ------------------------------------------------------------------ epilogue: + b2, + x, full-row stores
     const int qlen = a.rs.len[t.seg];
-    f32x4 xres[16];
+    constexpr int XPT = C::ROWS * 64 / C::THREADS;   // float4 per thread (16)
+    f32x4 xres[XPT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int c = tid + QTHREADS * i, row = c >> 6, c4 = c & 63;
+    for (int i = 0; i < XPT; ++i) {
+        const int c = tid + C::THREADS * i, row = c >> 6, c4 = c & 63;
         xres[i] = *reinterpret_cast<const f32x4*>(a.X + (long long)(t.grow0 + row) * 256 + c4 * 4);
     }
-    __syncthreads();   // ring is dead; reuse the region as a [64][260] fp32 tile
+    __syncthreads();   // ring is dead; reuse the region as a [ROWS][260] fp32 tile
     {
         float* ot = reinterpret_cast<float*>(smem);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int col = (w + 4 * n) * 16 + lr;
+        for (int n = 0; n < C::NTB; ++n) {
+            const int col = (w + NW * n) * 16 + lr;
             const float b2 = a.b2[col];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ot[(mt * 16 + g * 4 + r) * OLD + col] = acc2[mt][n][r] + b2;
+                for (int r = 0; r < 4; ++r) ot[(mt * 16 + g * 4 + r) * C::OLD + col] = acc2[mt][n][r] + b2;
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int c = tid + QTHREADS * i, row = c >> 6, c4 = c & 63;
+        for (int i = 0; i < XPT; ++i) {
+            const int c = tid + C::THREADS * i, row = c >> 6, c4 = c & 63;
             if (t.r0 + row < qlen) {
-                const f32x4 d = *reinterpret_cast<const f32x4*>(ot + row * OLD + c4 * 4);
+                const f32x4 d = *reinterpret_cast<const f32x4*>(ot + row * C::OLD + c4 * 4);
                 *reinterpret_cast<f32x4*>(a.X + (long long)(t.grow0 + row) * 256 + c4 * 4) = xres[i] + d;
             }
         }
@@ -403,27 +378,25 @@ __global__ __launch_bounds__(QTHREADS, 2) void tail4_kernel(TailArgs a) {
     stamp(5);
 }
 
-template <int PREC> static hipError_t launch_tail4_prec(const TailArgs& a, hipStream_t s) {
-    typedef typename QT<PREC>::Tag Tag;
+template <int PREC, int NW, int MT> static hipError_t launch_tailx_t(const TailArgs& a, hipStream_t s) {
+    typedef TX<PREC, NW, MT> C;
     const int R = a.rs.B * (a.rs.cap0 + a.rs.cap1);
-    constexpr int SLOT = QT<PREC>::NPART * (64 / (8 * Tag::EPC)) * QBM * 128;
-    constexpr int region = 2 * SLOT > QBM * 260 * 4 ? 2 * SLOT : QBM * 260 * 4;
-    constexpr int smem = region + 4 * QBM * 4;
-    auto kern = tail4_kernel<PREC>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    auto kern = tailx_kernel<PREC, NW, MT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(R / QBM), dim3(QTHREADS), smem, s, a);
+    hipLaunchKernelGGL(kern, dim3(R / C::ROWS), dim3(C::THREADS), C::LDS, s, a);
     return hipGetLastError();
 }
-
-hipError_t launch_tail4(int prec, const TailArgs& a, hipStream_t s) {
+template <int NW, int MT> static hipError_t launch_tailx_p(int prec, const TailArgs& a, hipStream_t s) {
     switch (prec) {
-        case PREC_F32: return launch_tail4_prec<PREC_F32>(a, s);
-        case PREC_BF16: return launch_tail4_prec<PREC_BF16>(a, s);
-        case PREC_F16: return launch_tail4_prec<PREC_F16>(a, s);
-        case PREC_BF16X3: return launch_tail4_prec<PREC_BF16X3>(a, s);
+        case PREC_F32: return launch_tailx_t<PREC_F32, NW, MT>(a, s);
+        case PREC_BF16: return launch_tailx_t<PREC_BF16, NW, MT>(a, s);
+        case PREC_F16: return launch_tailx_t<PREC_F16, NW, MT>(a, s);
+        case PREC_BF16X3: return launch_tailx_t<PREC_BF16X3, NW, MT>(a, s);
     }
     return hipErrorInvalidValue;
 }
+hipError_t launch_tail4(int prec, const TailArgs& a, hipStream_t s) { return launch_tailx_p<4, 4>(prec, a, s); }
+hipError_t launch_tail128(int prec, const TailArgs& a, hipStream_t s) { return launch_tailx_p<8, 8>(prec, a, s); }
 
 }  // namespace lg

@@ -102,6 +102,20 @@ def test_unfused_path_matches_golden():
     np.testing.assert_allclose(out["matching_scores0"].cpu().numpy(), gold["matching_scores0"], atol=2e-4, rtol=0)
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+def test_streaming_tail_variants_match_golden(variant):
+    """lg_tail4.hip: <4 waves x 64 rows> and <8 waves x 128 rows> decompositions of the fused tail (engine option
+    tail_variant) are kept correct even though the default (lg_tail.hip) is the fastest."""
+    require_gpu()
+    meta, gold = load_golden("nonadaptive_bbox_300x200")
+    sd, data = make_golden.case_inputs(meta["case"])
+    model = gpu_util.make_model(sd, "fp32", **meta["case"]["conf"])
+    model.set_option("tail_variant", variant)
+    out = model(gpu_util.to_torch(data))
+    np.testing.assert_array_equal(out["matches0"].cpu().numpy(), gold["matches0"])
+    np.testing.assert_allclose(out["matching_scores0"].cpu().numpy(), gold["matching_scores0"], atol=2e-4, rtol=0)
+
+
 def test_plain_bf16_mismatch_rate_is_reported_not_hidden():
     """precision='bf16' (single bf16 MFMA everywhere) is the fast mode; it does NOT hold the 1e-3 bar.
     Assert the documented envelope: <= 2 % index flips, |dscore| <= 0.5."""

@@ -354,7 +354,8 @@ int lg_engine_finalize_weights(lg_engine* e) {
     total = ((total + 255) & ~size_t(255)) + L * sqkv_layer; total = ((total + 255) & ~size_t(255)) + L * cqkv_layer;
     addf((size_t)L * 512); addf((size_t)L * 512);
     total += 4096;
-    if (e->w_arena) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(e->w_arena)); e->w_arena = nullptr; }
+    HIPCHK(hipDeviceSynchronize());   // weights may be in use by forwards still running on any stream
+    if (e->w_arena) { HIPCHK(hipFree(e->w_arena)); e->w_arena = nullptr; }
     HIPCHK(hipMalloc(&e->w_arena, total));
     HIPCHK(hipMemset(e->w_arena, 0, total));
     DevArena ar{static_cast<char*>(e->w_arena), total, 0};

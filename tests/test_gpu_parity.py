@@ -102,6 +102,41 @@ def test_unfused_path_matches_golden():
     np.testing.assert_allclose(out["matching_scores0"].cpu().numpy(), gold["matching_scores0"], atol=2e-4, rtol=0)
 
 
+def test_adaptive_batch_against_oracle_loop():
+    """Batch extension (every pair stops / prunes on its own) against the oracle's loop of B = 1 calls, mixed sizes,
+    fp32 mode: indices, stop layers and prune counters must be identical pair by pair."""
+    require_gpu()
+    sd = synth.make_state_dict(0, recipe="B")
+    data = synth.make_batch(321, 3, 420, 380)
+    conf = O.make_conf(pruning_min_kpts=-1)
+    ref = O.forward(sd, conf, data)
+    model = gpu_util.make_model(sd, "fp32", pruning_min_kpts=-1)
+    out = model(gpu_util.to_torch(data))
+    np.testing.assert_array_equal(out["matches0"].cpu().numpy(), ref["matches0"])
+    np.testing.assert_array_equal(out["matches1"].cpu().numpy(), ref["matches1"])
+    assert out["stop"].cpu().tolist() == ref["stop"]
+    np.testing.assert_array_equal(out["prune0"].cpu().numpy(), ref["prune0"])
+    np.testing.assert_array_equal(out["prune1"].cpu().numpy(), ref["prune1"])
+    np.testing.assert_allclose(out["matching_scores0"].cpu().numpy(), ref["matching_scores0"], atol=2e-4, rtol=0)
+    assert len(set(ref["stop"])) >= 1
+
+
+def test_three_layer_model_and_no_image_size():
+    """n_layers != 9 and bounding-box normalisation (no image_size, ref :35-36) against the oracle."""
+    require_gpu()
+    sd = synth.make_state_dict(11, recipe="A", n_layers=3)
+    data = synth.make_batch(77, 2, 150, 170)
+    for k in ("image0", "image1"):
+        data[k].pop("image_size")
+    conf = O.make_conf(n_layers=3, depth_confidence=-1, width_confidence=-1)
+    ref = O.forward(sd, conf, data)
+    model = gpu_util.make_model(sd, "fp32", n_layers=3, depth_confidence=-1, width_confidence=-1)
+    out = model(gpu_util.to_torch(data))
+    np.testing.assert_array_equal(out["matches0"].cpu().numpy(), ref["matches0"])
+    np.testing.assert_allclose(out["matching_scores0"].cpu().numpy(), ref["matching_scores0"], atol=2e-4, rtol=0)
+    assert (out["prune0"] == 3).all()
+
+
 @pytest.mark.parametrize("variant", [1, 2])
 def test_streaming_tail_variants_match_golden(variant):
     """lg_tail4.hip: <4 waves x 64 rows> and <8 waves x 128 rows> decompositions of the fused tail (engine option

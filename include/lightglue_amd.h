@@ -69,6 +69,17 @@ typedef struct lg_forward_io {
     int32_t *matches;                      /* [B][min(n0,n1)][2] sorted by index0                 */
     float *match_scores;                   /* [B][min(n0,n1)]                                     */
     int32_t *n_matches;                    /* [B]                                                 */
+    /* Ragged batches (replaces the reference's pad_to_length ones-padding + masks,
+     * lightglue.py:46-55, :512-520): optional per-pair keypoint counts, num0[b] <= n0, num1[b] <= n1.
+     * Rows >= num of the dense inputs are never read; their outputs are -1 / 0 (prune counters 0).
+     * Each pair behaves exactly as a separate B=1 call on its first num rows.  NULL = all rows live. */
+    const int32_t *num0, *num1;            /* [B] or NULL                                         */
+    /* Optional side output: the full log-assignment matrix of
+     * sigmoid_log_double_softmax (lightglue.py:265-277) INCLUDING the dustbin row / column, in ORIGINAL
+     * keypoint index space: [B][n0+1][n1+1] fp32.  Rows / columns of keypoints that were pruned (or are
+     * padding of a ragged batch) hold -inf; the corner is 0 as in the reference.  NULL = not produced
+     * (the match outputs never need the matrix materialised). */
+    float *log_assignment;
 } lg_forward_io;
 
 /* Last error message of the calling thread (never NULL). */
@@ -119,6 +130,18 @@ const char* lg_profile_class_name(int32_t cls);
 int lg_engine_profile_enable(lg_engine* e, int32_t on);
 /* Accumulated milliseconds and launch-site counts per class since the last read (resets). */
 int lg_engine_profile_read(lg_engine* e, double* ms, int64_t* count, int32_t n_classes);
+
+/* ---- SuperPoint descriptor head: the producer of the matcher's descriptor tensors ----
+ * Replaces, for descriptor_dim 256 and cell size s (8), the tail of SuperPoint.forward
+ * (lightglue/superpoint.py:216-228): optional dense L2 normalisation of the descriptor map (:218),
+ * sample_descriptors (:80-95: bilinear grid_sample with align_corners=True and zero padding + L2
+ * normalisation) and the transpose to [B][N][256] (:228).  Stateless; all pointers are device pointers.
+ *   desc_map   [B][256][h][w] fp32 (NCHW)         keypoints [B][N][2] fp32 pixel (x, y)
+ *   num        [B] live keypoints per image or NULL; rows >= num[b] of `out` are zero-filled
+ *   workspace  [B][h][w][256] fp32 scratch          out       [B][N][256] fp32 */
+int lg_sp_sample_descriptors(const float* desc_map, int32_t batch, int32_t channels, int32_t h, int32_t w,
+                             const float* keypoints, const int32_t* num, int32_t n, int32_t cell,
+                             int32_t normalize_dense, float* workspace, float* out, void* hip_stream);
 
 #ifdef __cplusplus
 }

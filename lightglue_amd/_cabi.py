@@ -24,6 +24,7 @@ EXPORTED_SYMBOLS = (
     "lg_engine_finalize_weights", "lg_engine_reserve", "lg_engine_forward", "lg_engine_set_option",
     "lg_engine_debug_stop_after", "lg_engine_debug_read", "lg_engine_debug_caps",
     "lg_profile_num_classes", "lg_profile_class_name", "lg_engine_profile_enable", "lg_engine_profile_read",
+    "lg_sp_sample_descriptors",
 )
 
 
@@ -46,6 +47,7 @@ class LgForwardIO(C.Structure):
         ("scales0", _fp), ("oris0", _fp), ("scales1", _fp), ("oris1", _fp),
         ("matches0", _fp), ("matches1", _fp), ("scores0", _fp), ("scores1", _fp), ("stop", _fp),
         ("prune0", _fp), ("prune1", _fp), ("matches", _fp), ("match_scores", _fp), ("n_matches", _fp),
+        ("num0", _fp), ("num1", _fp), ("log_assignment", _fp),
     ]
 
 
@@ -88,6 +90,8 @@ def load() -> C.CDLL:
     lib.lg_profile_class_name.argtypes = [C.c_int32]
     lib.lg_engine_profile_enable.argtypes = [C.c_void_p, C.c_int32]
     lib.lg_engine_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]
+    lib.lg_sp_sample_descriptors.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                             C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
 

@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void adapt_decide_kernel(AdaptArgs a) {
     const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ int sh_cnt[4];
     __shared__ int sh_stop;
+    __shared__ int sh_newlen[2];
     if (!a.active[pair]) return;
     const int len0 = a.len[2 * pair], len1 = a.len[2 * pair + 1];
 
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void adapt_decide_kernel(AdaptArgs a) {
         __syncthreads();
         if (tid == 0) {
             const int total = sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
-            const float ratio = 1.0f - (float)total / (float)(a.n0 + a.n1);
+            const float ratio = 1.0f - (float)total / (float)(a.len_orig[2 * pair] + a.len_orig[2 * pair + 1]);
             const int stop = ratio > a.depth_conf;
             sh_stop = stop;
             if (stop) { a.active[pair] = 0; a.final_layer[pair] = a.layer; }
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void adapt_decide_kernel(AdaptArgs a) {
         const int seg = 2 * pair + image;
         const int L = image ? len1 : len0;
         if (!a.do_prune || L <= a.pruning_min_kpts) {   // ref :551 / :559
-            if (tid == 0) a.len_old[seg] = -1;          // "pruning not applied at this layer"
+            if (tid == 0) { a.len_old[seg] = -1; sh_newlen[image] = L; }   // "pruning not applied at this layer"
             continue;
         }
         const int base = seg_row_base(a.rs, seg);
@@ -76,8 +77,11 @@ __global__ __launch_bounds__(256) void adapt_decide_kernel(AdaptArgs a) {
             running += sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
         }
         __syncthreads();
-        if (tid == 0) { a.len_old[seg] = L; a.len[seg] = running; }
+        if (tid == 0) { a.len_old[seg] = L; a.len[seg] = running; sh_newlen[image] = running; }
     }
+    // every point of one image pruned: the reference leaves its layer loop at the next iteration's
+    // empty guard (ref :539-540) and returns the empty result with stop = layer + 2 (ref :568-588)
+    if (tid == 0 && (sh_newlen[0] == 0 || sh_newlen[1] == 0)) { a.active[pair] = 0; a.final_layer[pair] = a.layer + 1; }
 }
 
 __global__ __launch_bounds__(256) void adapt_compact_kernel(AdaptArgs a) {

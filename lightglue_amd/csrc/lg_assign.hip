@@ -234,6 +234,30 @@ __global__ __launch_bounds__(256) void finalize_kernel(AssignArgs a) {
     if (tid == 0) a.n_matches[pair] = running;
 }
 
+// ---- optional: materialise the full log-assignment (ref :265-277) in original index space.
+// grid (cap0 + 1, B): block r < cap0 writes score row r (+ its dustbin column entry), block cap0 the dustbin row.
+__global__ __launch_bounds__(256) void fill_neg_inf_kernel(float* p, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = -INFINITY;
+}
+__global__ __launch_bounds__(256) void log_assignment_kernel(AssignArgs a) {
+    const int pair = blockIdx.y, r = blockIdx.x, tid = threadIdx.x;
+    const int len0 = a.rs.len[2 * pair], len1 = a.rs.len[2 * pair + 1];
+    const int base0 = seg_row_base(a.rs, 2 * pair), base1 = seg_row_base(a.rs, 2 * pair + 1);
+    float* out = a.log_assignment + (long long)pair * (a.n0 + 1) * (a.n1 + 1);
+    if (r == a.rs.cap0) {   // dustbin row: logsigmoid(-z1) (ref :276), corner 0 (ref :269 zero-initialised)
+        for (int c = tid; c < len1; c += 256) out[(long long)a.n0 * (a.n1 + 1) + a.ind[base1 + c]] = a.lsneg[base1 + c];
+        if (tid == 0) out[(long long)a.n0 * (a.n1 + 1) + a.n1] = 0.f;
+        return;
+    }
+    if (r >= len0) return;
+    float* orow = out + (long long)a.ind[base0 + r] * (a.n1 + 1);
+    const float* simr = a.sim + ((long long)pair * a.rs.cap0 + r) * a.rs.cap1;
+    const float lr = a.lse_r[(long long)pair * a.rs.cap0 + r], l0 = a.ls[base0 + r];
+    const float* lsec = a.lse_c + (long long)pair * a.rs.cap1;
+    for (int c = tid; c < len1; c += 256) orow[a.ind[base1 + c]] = score_of(simr[c], lr, lsec[c], l0 + a.ls[base1 + c]);
+    if (tid == 0) orow[a.n1] = a.lsneg[base0 + r];   // dustbin column: logsigmoid(-z0) (ref :275)
+}
+
 hipError_t launch_assign(const AssignArgs& a, hipStream_t s) {
     const int B = a.rs.B;
     hipError_t e;
@@ -250,6 +274,11 @@ hipError_t launch_assign(const AssignArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(argmax_sweep_kernel, dim3(a.rs.cap0 / ART, B), dim3(256), 0, s, a);
     hipLaunchKernelGGL(col_argmax_merge_kernel, dim3((a.rs.cap1 + 255) / 256, B), dim3(256), 0, s, a);
     hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(256), 0, s, a);
+    if (a.log_assignment) {
+        const long long total = (long long)B * (a.n0 + 1) * (a.n1 + 1);
+        hipLaunchKernelGGL(fill_neg_inf_kernel, dim3(2048), dim3(256), 0, s, a.log_assignment, total);
+        hipLaunchKernelGGL(log_assignment_kernel, dim3(a.rs.cap0 + 1, B), dim3(256), 0, s, a);
+    }
     return hipGetLastError();
 }
 

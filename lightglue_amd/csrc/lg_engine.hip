@@ -104,7 +104,7 @@ struct lg_engine {
     float *X, *CTX, *MSG, *H1, *G, *COS, *SIN, *MD, *SIM, *LS, *CONF, *MSCORE, *LSE_R, *LSE_C, *MAX0, *MAX1, *BBOX, *XIN, *CPM, *CPS, *CBV;
     int* CBI;
     void *Q, *K, *VT;
-    int *IND, *DST, *LEN, *LEN_OLD, *ACTIVE, *FINAL_LAYER, *ARG0, *ARG1;
+    int *IND, *DST, *LEN, *LEN_ORIG, *LEN_OLD, *ACTIVE, *FINAL_LAYER, *ARG0, *ARG1;
     int debug_stop = -1;
     // ---- per-kernel-class HIP-event timing (bench.py roofline leg)
     bool profiling = false;
@@ -171,12 +171,21 @@ const HostTensor* find(const lg_engine* e, const std::string& name, std::initial
     return &it->second;
 }
 
-__global__ void init_state_kernel(int B, int n0, int n1, int L, int* len, int* len_old, int* active, int* final_layer,
-                                  int* prune0, int* prune1) {
+__global__ void init_state_kernel(int B, int n0, int n1, int L, const int* num0, const int* num1, int* len, int* len_orig, int* len_old,
+                                  int* active, int* final_layer, int* prune0, int* prune1) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (len && i < B) { len[2 * i] = n0; len[2 * i + 1] = n1; len_old[2 * i] = -1; len_old[2 * i + 1] = -1; active[i] = 1; final_layer[i] = L - 1; }
-    if (prune0) for (long long k = i; k < (long long)B * n0; k += (long long)gridDim.x * blockDim.x) prune0[k] = 1;
-    if (prune1) for (long long k = i; k < (long long)B * n1; k += (long long)gridDim.x * blockDim.x) prune1[k] = 1;
+    auto count = [](const int* num, int pair, int n) { int v = num ? num[pair] : n; return v < 0 ? 0 : (v > n ? n : v); };
+    if (len && i < B) {
+        const int l0 = count(num0, i, n0), l1 = count(num1, i, n1);
+        len[2 * i] = l0; len[2 * i + 1] = l1; len_orig[2 * i] = l0; len_orig[2 * i + 1] = l1;
+        len_old[2 * i] = -1; len_old[2 * i + 1] = -1;
+        // a pair with an empty image never enters the layer loop: stop = 1, empty result (ref :539-540, :568-588)
+        const int live = l0 > 0 && l1 > 0;
+        active[i] = live; final_layer[i] = live ? L - 1 : 0;
+    }
+    // prune counters start at 1 for every keypoint (ref :535-536); padding rows of a ragged batch get 0
+    if (prune0) for (long long k = i; k < (long long)B * n0; k += (long long)gridDim.x * blockDim.x) prune0[k] = (int)(k % n0) < count(num0, (int)(k / n0), n0);
+    if (prune1) for (long long k = i; k < (long long)B * n1; k += (long long)gridDim.x * blockDim.x) prune1[k] = (int)(k % n1) < count(num1, (int)(k / n1), n1);
 }
 __global__ void write_stop_kernel(int B, const int* final_layer, int* stop) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -207,7 +216,7 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
         add(R * (size_t)e->cfg.input_dim * 4);                  // XIN
         for (int i = 0; i < 3; ++i) add(R * 256 * as);          // Q K VT
         add(R * 4); add(R * 4);                                 // IND DST
-        for (int i = 0; i < 4; ++i) add((size_t)nB * 2 * 4);    // LEN LEN_OLD ACTIVE FINAL_LAYER
+        for (int i = 0; i < 5; ++i) add((size_t)nB * 2 * 4);    // LEN LEN_ORIG LEN_OLD ACTIVE FINAL_LAYER
         add(R / 64 * 64 * 8);                                   // TAILDBG
         total += 4096;
         HIPCHK(hipMalloc(&e->ws, total));
@@ -235,7 +244,7 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
     e->XIN = (float*)take("XIN", R * (size_t)e->cfg.input_dim * 4);
     e->Q = take("Q", R * 256 * as); e->K = take("K", R * 256 * as); e->VT = take("VT", R * 256 * as);
     e->IND = (int*)take("IND", R * 4); e->DST = (int*)take("DST", R * 4);
-    e->LEN = (int*)take("LEN", (size_t)B * 2 * 4); e->LEN_OLD = (int*)take("LEN_OLD", (size_t)B * 2 * 4);
+    e->LEN = (int*)take("LEN", (size_t)B * 2 * 4); e->LEN_ORIG = (int*)take("LEN_ORIG", (size_t)B * 2 * 4); e->LEN_OLD = (int*)take("LEN_OLD", (size_t)B * 2 * 4);
     e->ACTIVE = (int*)take("ACTIVE", (size_t)B * 4); e->FINAL_LAYER = (int*)take("FINAL_LAYER", (size_t)B * 4);
     e->TAILDBG = (long long*)take("TAILDBG", R / 64 * 64 * 8);
     if (ar.used > e->ws_bytes) return fail(LG_ERR_STATE, "workspace carve overflow");
@@ -292,7 +301,7 @@ int lg_engine_profile_read(lg_engine* e, double* ms, int64_t* count, int32_t n) 
 }
 
 const char* lg_last_error(void) { return g_err.c_str(); }
-const char* lg_version(void) { return "lightglue_amd 0.1 (gfx950)"; }
+const char* lg_version(void) { return "lightglue_amd 0.2 (gfx950)"; }
 
 int lg_engine_create(const lg_config* cfg, lg_engine** out) {
     if (!cfg || !out) return fail(LG_ERR_INVALID, "null argument");
@@ -496,6 +505,17 @@ int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
 
 int lg_engine_debug_stop_after(lg_engine* e, int32_t step) { if (!e) return fail(LG_ERR_INVALID, "null engine"); e->debug_stop = step; return LG_OK; }
 
+int lg_sp_sample_descriptors(const float* desc_map, int32_t batch, int32_t channels, int32_t h, int32_t w, const float* keypoints,
+                             const int32_t* num, int32_t n, int32_t cell, int32_t normalize_dense, float* workspace, float* out,
+                             void* hip_stream) {
+    if (channels != 256) return fail(LG_ERR_INVALID, "descriptor map must have 256 channels");
+    if (batch < 1 || h < 1 || w < 1 || n < 0 || cell < 1) return fail(LG_ERR_INVALID, "bad descriptor map / keypoint sizes");
+    if (!desc_map || !workspace || (n && (!keypoints || !out))) return fail(LG_ERR_INVALID, "null pointer");
+    SpArgs a{desc_map, workspace, keypoints, num, out, batch, h, w, n, cell, normalize_dense ? 1 : 0};
+    HIPCHK(launch_sp_sample(a, static_cast<hipStream_t>(hip_stream)));
+    return LG_OK;
+}
+
 int lg_engine_debug_caps(lg_engine* e, int32_t* cap0, int32_t* cap1) {
     if (!e || !cap0 || !cap1) return fail(LG_ERR_INVALID, "null argument");
     *cap0 = e->cur_cap0; *cap1 = e->cur_cap1;
@@ -535,7 +555,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
         if (n0) { HIPCHK(hipMemsetAsync(io->matches0, 0xFF, sizeof(int) * (size_t)B * n0, s)); HIPCHK(hipMemsetAsync(io->scores0, 0, 4 * (size_t)B * n0, s)); }
         if (n1) { HIPCHK(hipMemsetAsync(io->matches1, 0xFF, sizeof(int) * (size_t)B * n1, s)); HIPCHK(hipMemsetAsync(io->scores1, 0, 4 * (size_t)B * n1, s)); }
         HIPCHK(hipMemsetAsync(io->n_matches, 0, sizeof(int) * (size_t)B, s));
-        hipLaunchKernelGGL(init_state_kernel, dim3(64), dim3(256), 0, s, B, n0, n1, L, nullptr, nullptr, nullptr, nullptr,
+        hipLaunchKernelGGL(init_state_kernel, dim3(64), dim3(256), 0, s, B, n0, n1, L, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                            (do_prune && n0) ? io->prune0 : nullptr, (do_prune && n1) ? io->prune1 : nullptr);
         // stop = 1 for every pair
         std::vector<int> ones(B, 1);
@@ -554,7 +574,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
     int step = 0;
 #define STEP_DONE() do { if (e->debug_stop >= 0 && step >= e->debug_stop) return LG_OK; ++step; } while (0)
 
-    hipLaunchKernelGGL(init_state_kernel, dim3(64), dim3(256), 0, s, B, n0, n1, L, e->LEN, e->LEN_OLD, e->ACTIVE, e->FINAL_LAYER,
+    hipLaunchKernelGGL(init_state_kernel, dim3(64), dim3(256), 0, s, B, n0, n1, L, io->num0, io->num1, e->LEN, e->LEN_ORIG, e->LEN_OLD, e->ACTIVE, e->FINAL_LAYER,
                        do_prune ? io->prune0 : nullptr, do_prune ? io->prune1 : nullptr);
     {
         PrepArgs p{};
@@ -677,7 +697,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
             TRY(prof_end(e, s));
             AdaptArgs ad{};
             ad.rs = rs_act; ad.len = e->LEN; ad.active = e->ACTIVE; ad.len_old = e->LEN_OLD; ad.final_layer = e->FINAL_LAYER;
-            ad.ind = e->IND; ad.dst = e->DST; ad.prune0 = io->prune0; ad.prune1 = io->prune1; ad.n0 = n0; ad.n1 = n1;
+            ad.ind = e->IND; ad.dst = e->DST; ad.prune0 = io->prune0; ad.prune1 = io->prune1; ad.n0 = n0; ad.n1 = n1; ad.len_orig = e->LEN_ORIG;
             ad.conf = e->CONF; ad.mscore = e->MSCORE; ad.X = e->X; ad.cosb = e->COS; ad.sinb = e->SIN;
             ad.layer = i;
             // ref :631-634 threshold (float32 buffer), :656 and :640 compare in float32
@@ -696,6 +716,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
         RowDotArgs rd{};
         rd.rs = rs_all; rd.X = e->X; rd.w0 = e->w_match; rd.b0 = e->b_match; rd.out0 = e->LS; rd.act0 = 2;
         rd.layer_of_pair = e->FINAL_LAYER; rd.w_layer_stride = D; rd.ignore_active = 1;
+        if (io->log_assignment) { rd.w1 = e->w_match; rd.b1 = e->b_match; rd.out1 = e->MSCORE; rd.act1 = 3; }  // dustbin terms
         TRY(prof_begin(e, PC_ROWDOT, s));
         HIPCHK(launch_rowdot(rd, s));
         TRY(prof_end(e, s));
@@ -713,6 +734,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
         as.max1 = e->MAX1; as.arg1 = e->ARG1; as.cpm = e->CPM; as.cps = e->CPS; as.cbv = e->CBV; as.cbi = e->CBI; as.ind = e->IND; as.n0 = n0; as.n1 = n1; as.filter_threshold = (float)e->cfg.filter_threshold;
         as.m0 = io->matches0; as.m1 = io->matches1; as.s0 = io->scores0; as.s1 = io->scores1;
         as.matches = io->matches; as.mscores = io->match_scores; as.n_matches = io->n_matches; as.max_matches = max_matches;
+        as.log_assignment = io->log_assignment; as.lsneg = e->MSCORE;
         TRY(prof_begin(e, PC_ASSIGN, s));
         HIPCHK(launch_assign(as, s));
         TRY(prof_end(e, s));

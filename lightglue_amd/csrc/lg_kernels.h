@@ -104,7 +104,7 @@ hipError_t launch_ln_gelu(const LnGeluArgs& a, hipStream_t s);
 // z[row] = x[row,:] . w + b for up to two weight vectors at once (token confidence, matchability)
 struct RowDotArgs {
     RowSpace rs; const float* X;
-    const float* w0; const float* b0; float* out0; int act0;   // act: 0 raw, 1 sigmoid, 2 logsigmoid
+    const float* w0; const float* b0; float* out0; int act0;   // act: 0 raw, 1 sigmoid, 2 logsigmoid(z), 3 logsigmoid(-z)
     const float* w1; const float* b1; float* out1; int act1;   // w1 == nullptr -> skipped
     const int* layer_of_pair; int w_layer_stride;              // optional per-pair layer select
     int ignore_active;
@@ -119,6 +119,7 @@ struct AdaptArgs {
     int* ind; int* dst;     // [R]
     int* prune0; int* prune1;   // [B][n0], [B][n1] layer counters in ORIGINAL index space
     int n0, n1;
+    const int* len_orig;    // [2B] keypoint counts the pair started with (the m + n of ref :550)
     const float* conf; const float* mscore;   // [R] token confidence / matchability (sigmoid)
     float* X; float* cosb; float* sinb;
     int layer; float conf_thr; float depth_conf; float width_conf; int pruning_min_kpts;
@@ -143,7 +144,20 @@ struct AssignArgs {
     int* m0; int* m1; float* s0; float* s1;   // [B][n0], [B][n1]
     // compact match list (sorted by index0): [B][min(n0,n1)][2] + count
     int* matches; float* mscores; int* n_matches; int max_matches;
+    // optional full log-assignment [B][n0+1][n1+1] (ref :265-277) + logsigmoid(-z) per row for its dustbins
+    float* log_assignment; const float* lsneg;
 };
 hipError_t launch_assign(const AssignArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- SuperPoint descriptor head (lg_superpoint.hip)
+struct SpArgs {
+    const float* desc_map;     // [B][256][h][w] dense descriptor map (NCHW, as the conv stack leaves it)
+    float* nhwc;               // [B][h][w][256] workspace: (normalised) location-major copy
+    const float* keypoints;    // [B][N][2] pixel (x, y)
+    const int* num;            // [B] live keypoints per image or nullptr
+    float* out;                // [B][N][256]
+    int B, h, w, N, s, normalize_dense;
+};
+hipError_t launch_sp_sample(const SpArgs& a, hipStream_t s);
 
 }  // namespace lg

@@ -12,8 +12,9 @@ __global__ __launch_bounds__(256) void bbox_kernel(PrepArgs a) {
     const int seg = blockIdx.x, image = seg & 1, pair = seg >> 1;
     const int n = image ? a.n1 : a.n0;
     const float* kp = (image ? a.kpts1 : a.kpts0) + (long long)pair * n * 2;
+    const int live = a.rs.len[seg];   // ragged batch: only the pair's own keypoints define its bounding box
     float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
-    for (int i = threadIdx.x; i < n; i += 256) {
+    for (int i = threadIdx.x; i < live; i += 256) {
         const float x = kp[2 * i], y = kp[2 * i + 1];
         mnx = fminf(mnx, x); mny = fminf(mny, y); mxx = fmaxf(mxx, x); mxy = fmaxf(mxy, y);
     }
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
     const int seg = blockIdx.y, image = seg & 1, pair = seg >> 1;
     const int n = image ? a.n1 : a.n0;
     const int r = blockIdx.x * 4 + wave;
-    if (r >= n) return;
+    if (r >= a.rs.len[seg]) return;   // len <= n: rows past a pair's own count are padding (never read)
     const long long grow = seg_row_base(a.rs, seg) + r;
     const float* kp = (image ? a.kpts1 : a.kpts0) + ((long long)pair * n + r) * 2;
     const float* szp = image ? a.size1 : a.size0;
@@ -111,6 +112,7 @@ hipError_t launch_ln_gelu(const LnGeluArgs& a, hipStream_t s) {
 __device__ __forceinline__ float act_apply(float z, int act) {
     if (act == 1) return 1.f / (1.f + expf(-z));                    // sigmoid
     if (act == 2) return fminf(z, 0.f) - log1pf(expf(-fabsf(z)));   // logsigmoid
+    if (act == 3) return fminf(-z, 0.f) - log1pf(expf(-fabsf(z)));  // logsigmoid(-z): dustbin terms (ref :275-276)
     return z;
 }
 __global__ __launch_bounds__(256) void rowdot_kernel(RowDotArgs a, int R) {

@@ -41,3 +41,55 @@ def match_pair(extractor, matcher, image0: torch.Tensor, image1: torch.Tensor, d
     matches01 = matcher({"image0": feats[0], "image1": feats[1]})
     feats0, feats1, matches01 = (batch_to_device(rbd(d), device) for d in (feats[0], feats[1], matches01))
     return feats0, feats1, matches01
+
+
+_PER_KEYPOINT = ("keypoints", "descriptors", "scales", "oris", "keypoint_scores")
+
+
+def collate_features(feats: list) -> Dict[str, Any]:
+    """Stack per-image feature dicts with DIFFERENT keypoint counts into one ragged batch for `LightGlue.forward`.
+
+    Each item follows the extractor contract (reference `lightglue/utils.py:136-147`), with or without the leading
+    batch dimension of 1: `keypoints [N_i,2]`, `descriptors [N_i,D]`, optional `scales`/`oris`/`keypoint_scores
+    [N_i]` and `image_size [2]`.  Per-keypoint tensors are zero-padded to max N_i and `num_keypoints [B]` carries
+    the true counts; the engine never reads the padding (the reference instead pads with ones and masks every
+    attention call, `lightglue.py:46-55, 512-520`, and only inside `compile()`d B=1 calls)."""
+    items = []
+    for f in feats:
+        kp = f["keypoints"]
+        items.append(rbd(f) if kp.dim() == 3 else f)
+    counts = [int(f["keypoints"].shape[0]) for f in items]
+    nmax = max(counts) if counts else 0
+    out: Dict[str, Any] = {}
+    for key in _PER_KEYPOINT:
+        if not all(key in f for f in items):
+            continue
+        first = items[0][key]
+        buf = first.new_zeros((len(items), nmax) + tuple(first.shape[1:]))
+        for b, f in enumerate(items):
+            buf[b, : counts[b]] = f[key]
+        out[key] = buf
+    if all("image_size" in f for f in items):
+        out["image_size"] = torch.stack([torch.as_tensor(f["image_size"], dtype=torch.float32).reshape(2) for f in items]).to(out["keypoints"].device)
+    out["num_keypoints"] = torch.tensor(counts, dtype=torch.int32, device=out["keypoints"].device)
+    return out
+
+
+def match_batch(matcher, feats0: list, feats1: list) -> list:
+    """Match B independent image pairs with ragged keypoint counts in ONE forward; returns one `rbd`-style result
+    dict per pair, trimmed to that pair's own keypoint counts (what B separate `matcher(...)` calls would give)."""
+    assert len(feats0) == len(feats1)
+    batch0, batch1 = collate_features(feats0), collate_features(feats1)
+    res = matcher({"image0": batch0, "image1": batch1})
+    n0, n1 = batch0["num_keypoints"].tolist(), batch1["num_keypoints"].tolist()
+    out = []
+    for b in range(len(feats0)):
+        stop = res["stop"]
+        out.append({
+            "matches0": res["matches0"][b, : n0[b]], "matches1": res["matches1"][b, : n1[b]],
+            "matching_scores0": res["matching_scores0"][b, : n0[b]], "matching_scores1": res["matching_scores1"][b, : n1[b]],
+            "matches": res["matches"][b], "scores": res["scores"][b],
+            "prune0": res["prune0"][b, : n0[b]], "prune1": res["prune1"][b, : n1[b]],
+            "stop": int(stop[b]) if torch.is_tensor(stop) else stop,
+        })
+    return out

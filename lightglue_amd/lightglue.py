@@ -145,6 +145,8 @@ class LightGlue(nn.Module):
             self.load_state_dict(self.rename_legacy_keys(state_dict, L), strict=False)
 
         self.static_lengths = None
+        # extension: also return the full [B, M+1, N+1] log-assignment incl. dustbins (ref :265-277)
+        self.return_log_assignment = False
         self._engine = None  # (handle, device_index, config signature)
         self._weights_sig = None
         self._plist = None
@@ -278,7 +280,10 @@ class LightGlue(nn.Module):
         """Match keypoints and descriptors between two images (same dict contract as ref :456-481).
 
         Input (dict):  image0/image1: {keypoints [B,N,2], descriptors [B,N,D], image_size [B,2] (optional),
-                                       scales/oris [B,N] iff add_scale_ori}
+                                       scales/oris [B,N] iff add_scale_ori,
+                                       num_keypoints [B] int (optional, extension: ragged batch — pair b uses only
+                                       its first num_keypoints[b] rows and behaves exactly like a separate B=1
+                                       call on them; padding rows come back as -1 / 0, see glue.collate_features)}
         Output (dict): matches0 [B,M] int64, matching_scores0 [B,M], matches1 [B,N], matching_scores1 [B,N],
                        matches List[[S_i,2]], scores List[[S_i]], stop, prune0 [B,M], prune1 [B,N]
         """
@@ -313,6 +318,16 @@ class LightGlue(nn.Module):
         if conf.add_scale_ori:
             extra = [f32(d0["scales"]), f32(d0["oris"]), f32(d1["scales"]), f32(d1["oris"])]
 
+        def as_count(c, nmax):
+            if c is None:
+                return None
+            c = torch.as_tensor(c).detach().to(device=device, dtype=torch.int32).contiguous()
+            assert c.shape == (b,), f"num_keypoints must have shape [{b}]"
+            return c.clamp(0, nmax)
+
+        num0, num1 = as_count(d0.get("num_keypoints"), m), as_count(d1.get("num_keypoints"), n)
+        ragged = num0 is not None or num1 is not None
+
         do_early_stop = conf.depth_confidence > 0
         do_compile = bool(self.static_lengths) and max(m, n) <= max(self.static_lengths)
         do_point_pruning = conf.width_confidence > 0 and not do_compile
@@ -330,6 +345,9 @@ class LightGlue(nn.Module):
         prune0 = torch.empty((b, m), **i32) if do_point_pruning else None
         prune1 = torch.empty((b, n), **i32) if do_point_pruning else None
 
+        log_assignment = None
+        if self.return_log_assignment and m > 0 and n > 0:
+            log_assignment = torch.empty((b, m + 1, n + 1), device=device, dtype=torch.float32)
         handle = self._get_engine(device)
         self._sync_weights(handle, device)
         ptr = lambda t: None if t is None or t.numel() == 0 else t.data_ptr()
@@ -338,7 +356,7 @@ class LightGlue(nn.Module):
             ptr(k0), ptr(k1), ptr(desc0), ptr(desc1), ptr(size0), ptr(size1),
             ptr(extra[0]), ptr(extra[1]), ptr(extra[2]), ptr(extra[3]),
             ptr(m0), ptr(m1), ptr(ms0), ptr(ms1), stop.data_ptr(), ptr(prune0), ptr(prune1),
-            ptr(mlist), ptr(mscore_list), n_matches.data_ptr())
+            ptr(mlist), ptr(mscore_list), n_matches.data_ptr(), ptr(num0), ptr(num1), ptr(log_assignment))
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             _cabi.check(_cabi.load().lg_engine_forward(handle, C.byref(io), C.c_void_p(stream)))
@@ -354,15 +372,21 @@ class LightGlue(nn.Module):
         else:  # ref :616-617
             prune0 = torch.full_like(ms0, float(conf.n_layers))
             prune1 = torch.full_like(ms1, float(conf.n_layers))
+            if num0 is not None:
+                prune0 = prune0 * (torch.arange(m, device=device)[None] < num0[:, None])
+            if num1 is not None:
+                prune1 = prune1 * (torch.arange(n, device=device)[None] < num1[:, None])
         stop64 = stop.long() if b > 1 else None
         counts = n_matches.tolist()  # host sync: the ragged lists need their sizes
         matches = [mlist64[k, : counts[k]] for k in range(b)]
         mscores = [mscore_list[k, : counts[k]] for k in range(b)]
-        if not do_early_stop and m > 0 and n > 0:
+        if not do_early_stop and m > 0 and n > 0 and not ragged:
             stop_out = conf.n_layers if b == 1 else torch.full((b,), conf.n_layers, device=device, dtype=torch.long)
         else:
             stop_out = int(stop[0].item()) if b == 1 else stop64
+        extra_out = {} if log_assignment is None else {"log_assignment": log_assignment}
         return {
+            **extra_out,
             "matches0": m0_64,
             "matches1": m1_64,
             "matching_scores0": ms0,

@@ -137,6 +137,106 @@ def test_three_layer_model_and_no_image_size():
     assert (out["prune0"] == 3).all()
 
 
+def _ragged_reference(sd, conf, data, counts0, counts1):
+    """The contract of a ragged batch: pair b == a separate B = 1 oracle call on its first counts[b] rows."""
+    refs = []
+    d0, d1 = data["image0"], data["image1"]
+    size = lambda d, b: np.asarray(d["image_size"])[b] if "image_size" in d else None
+    for b, (c0, c1) in enumerate(zip(counts0, counts1)):
+        refs.append(O.forward_pair(sd, conf, d0["keypoints"][b][:c0], d1["keypoints"][b][:c1],
+                                   d0["descriptors"][b][:c0], d1["descriptors"][b][:c1], size(d0, b), size(d1, b)))
+    return refs
+
+
+@pytest.mark.parametrize("mode", ["nonadaptive", "adaptive", "bbox"])
+def test_ragged_batch_equals_per_pair_calls(mode):
+    """num_keypoints per pair (incl. a 1-point image, an exact multiple of the tile size and an
+    EMPTY image inside the batch) — every pair must equal its own B = 1 oracle call; padding rows give -1 / 0."""
+    require_gpu()
+    counts0, counts1 = [300, 128, 1, 0, 257], [200, 333, 5, 77, 256]
+    nmax0, nmax1 = 320, 333
+    adaptive = mode == "adaptive"
+    sd = synth.make_state_dict(0, recipe="B" if adaptive else "A")
+    data = synth.make_batch(99, len(counts0), nmax0, nmax1)
+    kw = dict(pruning_min_kpts=64) if adaptive else dict(depth_confidence=-1, width_confidence=-1)
+    if mode == "bbox":
+        for k in ("image0", "image1"):
+            data[k].pop("image_size")
+    refs = _ragged_reference(sd, O.make_conf(**kw), data, counts0, counts1)
+    tdata = gpu_util.to_torch(data)
+    # poison the padding rows: the engine must never read them
+    for k, counts in (("image0", counts0), ("image1", counts1)):
+        for b, c in enumerate(counts):
+            tdata[k]["keypoints"][b, c:] = float("nan")
+            tdata[k]["descriptors"][b, c:] = float("nan")
+        tdata[k]["num_keypoints"] = torch.tensor(counts, dtype=torch.int32)
+    model = gpu_util.make_model(sd, "fp32", **kw)
+    out = model(tdata)
+    stops = out["stop"].cpu().tolist()
+    for b, ref in enumerate(refs):
+        c0, c1 = counts0[b], counts1[b]
+        m0, m1 = out["matches0"][b].cpu().numpy(), out["matches1"][b].cpu().numpy()
+        np.testing.assert_array_equal(m0[:c0], ref["matches0"]); np.testing.assert_array_equal(m1[:c1], ref["matches1"])
+        assert (m0[c0:] == -1).all() and (m1[c1:] == -1).all()
+        s0 = out["matching_scores0"][b].cpu().numpy()
+        np.testing.assert_allclose(s0[:c0], ref["matching_scores0"], atol=2e-4, rtol=0)
+        assert (s0[c0:] == 0).all()
+        assert stops[b] == ref["stop"], (b, stops[b], ref["stop"])
+        np.testing.assert_array_equal(out["prune0"][b].cpu().numpy()[:c0], ref["prune0"])
+        np.testing.assert_array_equal(out["prune1"][b].cpu().numpy()[:c1], ref["prune1"])
+        assert (out["prune0"][b].cpu().numpy()[c0:] == 0).all()
+        np.testing.assert_array_equal(out["matches"][b].cpu().numpy(), ref["matches"])
+    if adaptive:
+        assert any(r["prune0"].min(initial=99) < r["stop"] for r in refs if len(r["prune0"])), "fixture never pruned"
+    assert refs[3]["stop"] == 1 and stops[3] == 1   # empty image: ref :539-540
+
+
+def test_match_batch_helper_trims_to_own_counts():
+    require_gpu()
+    sd = synth.make_state_dict(0, recipe="A")
+    model = gpu_util.make_model(sd, "bf16x3", depth_confidence=-1, width_confidence=-1)
+    from lightglue_amd import match_batch
+    feats0, feats1, singles = [], [], []
+    for b, (c0, c1) in enumerate([(140, 90), (64, 200)]):
+        d = gpu_util.to_torch(synth.make_batch(5 + b, 1, c0, c1))
+        feats0.append(d["image0"]); feats1.append(d["image1"])
+        singles.append(model(d))
+    res = match_batch(model, feats0, feats1)
+    for r, one in zip(res, singles):
+        assert torch.equal(r["matches0"], one["matches0"][0]) and torch.equal(r["matches1"], one["matches1"][0])
+        assert torch.allclose(r["matching_scores0"], one["matching_scores0"][0], atol=1e-5)
+        assert torch.equal(r["matches"], one["matches"][0]) and r["stop"] == one["stop"]
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_full_log_assignment_output(adaptive):
+    """SURVEY.md §8 f4: optional [B, M+1, N+1] log-assignment incl. dustbins (ref :265-277) in original index space;
+    pruned keypoints hold -inf.  Checked entry by entry against the oracle's matrix."""
+    require_gpu()
+    sd = synth.make_state_dict(0, recipe="B" if adaptive else "A")
+    kw = dict(pruning_min_kpts=64) if adaptive else dict(depth_confidence=-1, width_confidence=-1)
+    data = synth.make_batch(7, 2, 333, 290)
+    model = gpu_util.make_model(sd, "fp32", **kw)
+    model.return_log_assignment = True
+    out = model(gpu_util.to_torch(data))
+    la = out["log_assignment"].cpu().numpy()
+    assert la.shape == (2, 334, 291)
+    conf = O.make_conf(**kw)
+    for b in range(2):
+        tr = {}
+        d0, d1 = data["image0"], data["image1"]
+        O.forward_pair(sd, conf, d0["keypoints"][b], d1["keypoints"][b], d0["descriptors"][b], d1["descriptors"][b],
+                       d0["image_size"][b], d1["image_size"][b], trace=tr)
+        full, i0, i1 = tr["scores_full"], tr["ind0"], tr["ind1"]
+        if adaptive:
+            assert len(i0) < 333 or len(i1) < 290, "fixture never pruned"
+        r = np.concatenate([i0, [333]]); c = np.concatenate([i1, [290]])
+        np.testing.assert_allclose(la[b][np.ix_(r, c)], full, atol=2e-4, rtol=0)
+        dead = np.ones((334, 291), bool); dead[np.ix_(r, c)] = False
+        assert np.isneginf(la[b][dead]).all()
+        assert la[b][333, 290] == 0.0
+
+
 @pytest.mark.parametrize("variant", [1, 2])
 def test_streaming_tail_variants_match_golden(variant):
     """lg_tail4.hip: <4 waves x 64 rows> and <8 waves x 128 rows> decompositions of the fused tail (engine option

@@ -122,3 +122,18 @@ def test_legacy_checkpoint_key_rename():
     assert not res.missing_keys and not res.unexpected_keys
     assert torch.equal(m.state_dict()["transformers.2.cross_attn.to_qk.weight"], legacy["cross_attn.2.to_qk.weight"])
     assert LightGlue.rename_legacy_keys(renamed, 3).keys() == renamed.keys()   # idempotent
+
+
+def test_collate_features_pads_and_counts():
+    """glue.collate_features: ragged per-image features -> one padded batch + num_keypoints."""
+    from lightglue_amd import collate_features
+    g = torch.Generator().manual_seed(0)
+    feats = [{"keypoints": torch.rand(n, 2, generator=g), "descriptors": torch.rand(n, 256, generator=g),
+              "keypoint_scores": torch.rand(n, generator=g), "image_size": torch.tensor([640.0, 480.0])} for n in (5, 9, 0)]
+    feats[1] = {k: v[None] for k, v in feats[1].items()}   # extractor output with batch dim 1 is accepted too
+    batch = collate_features(feats)
+    assert batch["keypoints"].shape == (3, 9, 2) and batch["descriptors"].shape == (3, 9, 256)
+    assert batch["num_keypoints"].tolist() == [5, 9, 0] and batch["num_keypoints"].dtype == torch.int32
+    assert batch["image_size"].shape == (3, 2)
+    assert torch.equal(batch["keypoints"][0, :5], feats[0]["keypoints"]) and (batch["keypoints"][0, 5:] == 0).all()
+    assert torch.equal(batch["descriptors"][1], feats[1]["descriptors"][0])

@@ -1,0 +1,91 @@
+"""SuperPoint descriptor head: oracle vs the reference's own outputs (CPU), HIP kernels vs both
+(GPU).  Tolerance: fp32 interpolation + normalisation, 2e-6 absolute on unit-norm descriptors."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import make_golden_superpoint as G
+from conftest import require_gpu
+from oracle import superpoint_oracle as SO
+
+GOLD = Path(__file__).resolve().parent / "golden"
+NAMES = sorted(G.CASES)
+TOL = 2e-6
+
+
+def load(name):
+    z = np.load(GOLD / f"{name}.npz")
+    seed, b, h, w, n = (int(v) for v in z["case"])
+    dense, kp = G.head_inputs(seed, b, h, w, n)
+    return z, dense, kp
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_matches_reference_fixture(name):
+    z, dense, kp = load(name)
+    np.testing.assert_allclose(SO.descriptor_head(kp, dense), z["descriptors"], atol=TOL, rtol=0)
+    if "sampled_unnormalized_map" in z:
+        np.testing.assert_allclose(SO.sample_descriptors(kp, dense), z["sampled_unnormalized_map"], atol=TOL, rtol=0)
+
+
+def test_cpu_tensors_raise():
+    from lightglue_amd import superpoint_head as H
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        H.descriptor_head(torch.zeros(1, 4, 2), torch.zeros(1, 256, 8, 8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_hip_descriptor_head_matches_reference_fixture(name):
+    require_gpu()
+    from lightglue_amd import superpoint_head as H
+    z, dense, kp = load(name)
+    kpt, dt = torch.from_numpy(kp).cuda(), torch.from_numpy(dense).cuda()
+    out = H.descriptor_head(kpt, dt)
+    assert out.shape == z["descriptors"].shape and out.is_contiguous()
+    np.testing.assert_allclose(out.cpu().numpy(), z["descriptors"], atol=TOL, rtol=0)
+    assert torch.equal(kpt.cpu(), torch.from_numpy(kp)), "inputs must not be modified"
+    if "sampled_unnormalized_map" in z:   # the reference-signature function: [b, c, N], no dense normalisation
+        np.testing.assert_allclose(H.sample_descriptors(kpt, dt).cpu().numpy(), z["sampled_unnormalized_map"], atol=TOL, rtol=0)
+
+
+@pytest.mark.gpu
+def test_hip_descriptor_head_ragged_and_odd_map():
+    """Ragged counts (padding rows zero, never read) and a map whose h*w is not a multiple of the 32-location tile."""
+    require_gpu()
+    from lightglue_amd import superpoint_head as H
+    dense, kp = G.head_inputs(5, 3, 13, 11, 40)
+    counts = [40, 17, 0]
+    ref = SO.descriptor_head(kp, dense)
+    kpt = torch.from_numpy(kp).cuda()
+    for b, c in enumerate(counts):
+        kpt[b, c:] = float("nan")
+    out = H.descriptor_head(kpt, torch.from_numpy(dense).cuda(), num_keypoints=torch.tensor(counts)).cpu().numpy()
+    for b, c in enumerate(counts):
+        np.testing.assert_allclose(out[b, :c], ref[b, :c], atol=TOL, rtol=0)
+        assert (out[b, c:] == 0).all()
+
+
+@pytest.mark.gpu
+def test_head_feeds_matcher():
+    """End to end: descriptor head output -> matcher, vs the oracle chain (descriptor oracle -> matcher oracle)."""
+    require_gpu()
+    import gpu_util
+    from lightglue_amd import superpoint_head as H
+    from lightglue_amd import synthetic as synth
+    from oracle import lightglue_oracle as O
+    dense, kp = G.head_inputs(9, 2, 48, 64, 256)
+    kp = kp[:, 14:]                                      # drop the deliberately out-of-image points
+    d = SO.descriptor_head(kp, dense)
+    sd = synth.make_state_dict(0, recipe="A")
+    conf = O.make_conf(depth_confidence=-1, width_confidence=-1)
+    size = np.array([512.0, 384.0], np.float32)
+    ref = O.forward_pair(sd, conf, kp[0], kp[1], d[0], d[1], size, size)
+    model = gpu_util.make_model(sd, "fp32", depth_confidence=-1, width_confidence=-1)
+    desc = H.descriptor_head(torch.from_numpy(kp).cuda(), torch.from_numpy(dense).cuda())
+    out = model({"image0": {"keypoints": torch.from_numpy(kp[:1]).cuda(), "descriptors": desc[:1], "image_size": torch.from_numpy(size)[None].cuda()},
+                 "image1": {"keypoints": torch.from_numpy(kp[1:]).cuda(), "descriptors": desc[1:], "image_size": torch.from_numpy(size)[None].cuda()}})
+    np.testing.assert_array_equal(out["matches0"][0].cpu().numpy(), ref["matches0"])
+    np.testing.assert_allclose(out["matching_scores0"][0].cpu().numpy(), ref["matching_scores0"], atol=2e-4, rtol=0)

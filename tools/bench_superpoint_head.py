@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Time the SuperPoint descriptor head (lg_superpoint.hip) against its HBM roofline.
+Workload: B images of 1024x768 (descriptor map 96x128x256) with N keypoints each.
+Algorithmic bytes: dense pass 2*4*256*h*w per image, sampling 5 KB per keypoint."""
+import json
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from lightglue_amd import superpoint_head as H  # noqa: E402
+
+B, h, w, N = (int(v) for v in (sys.argv[1:5] if len(sys.argv) >= 5 else (8, 96, 128, 2048)))
+g = torch.Generator(device="cuda").manual_seed(0)
+dense = torch.randn(B, 256, h, w, device="cuda", generator=g)
+kp = torch.rand(B, N, 2, device="cuda", generator=g) * torch.tensor([w * 8.0, h * 8.0], device="cuda")
+for _ in range(5):
+    H.descriptor_head(kp, dense)
+torch.cuda.synchronize()
+reps = 50
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    H.descriptor_head(kp, dense)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+bytes_alg = B * (2 * 4 * 256 * h * w + N * 5 * 1024)
+print(json.dumps({"workload": f"B={B} map={h}x{w}x256 N={N}", "ms": ms, "images_per_s": B / ms * 1e3,
+                  "algorithmic_GB": bytes_alg / 1e9, "achieved_GBps": bytes_alg / ms / 1e6, "frac_of_8TBps": bytes_alg / ms / 1e6 / 8000}))

@@ -231,7 +231,8 @@ def test_full_log_assignment_output(adaptive):
         if adaptive:
             assert len(i0) < 333 or len(i1) < 290, "fixture never pruned"
         r = np.concatenate([i0, [333]]); c = np.concatenate([i1, [290]])
-        np.testing.assert_allclose(la[b][np.ix_(r, c)], full, atol=2e-4, rtol=0)
+        # entries reach -150: fp32 dot products / LSEs carry a RELATIVE error, the match-relevant ones (near 0) 2e-4 abs
+        np.testing.assert_allclose(la[b][np.ix_(r, c)], full, atol=2e-4, rtol=1e-4)
         dead = np.ones((334, 291), bool); dead[np.ix_(r, c)] = False
         assert np.isneginf(la[b][dead]).all()
         assert la[b][333, 290] == 0.0

@@ -1,5 +1,5 @@
 """SuperPoint descriptor head: oracle vs the reference's own outputs (CPU), HIP kernels vs both
-(GPU).  Tolerance: fp32 interpolation + normalisation, 2e-6 absolute on unit-norm descriptors."""
+(GPU).  Tolerance: fp32 interpolation + normalisation, 5e-6 absolute on unit-norm descriptors."""
 from pathlib import Path
 
 import numpy as np
@@ -12,7 +12,7 @@ from oracle import superpoint_oracle as SO
 
 GOLD = Path(__file__).resolve().parent / "golden"
 NAMES = sorted(G.CASES)
-TOL = 2e-6
+TOL = 5e-6   # ix ~ 100 has an fp32 ulp of 7.6e-6: the interpolation weights differ by that between evaluation orders
 
 
 def load(name):

@@ -10,10 +10,14 @@ caller's stream right after the local forward.
 
 The ragged ``matches`` lists are rebuilt from ``matches0`` after the gather (no variable-size
 collective).
+
+Ragged batches (``num_keypoints`` per image) have unequal cost per pair, so for them the pairs are dealt to
+the ranks by estimated work (``balanced_shards``, SURVEY.md §8e "balance by expected work") instead of by
+contiguous blocks; the gather is the same single collective, followed by a row permutation.
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -26,8 +30,30 @@ def shard_range(batch: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def _slice_data(data: dict, lo: int, hi: int) -> dict:
-    return {k: ({kk: vv[lo:hi] for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in data.items()}
+def pair_cost(n0: int, n1: int, d: int = 256) -> float:
+    """Algorithmic FLOPs of one transformer layer for a pair with n0 / n1 keypoints: linear layers
+    2 490 368 per point, self-attention 4·d·n² per image, cross-attention 6·d·n0·n1."""
+    return 2490368.0 * (n0 + n1) + 4.0 * d * (n0 * n0 + n1 * n1) + 6.0 * d * n0 * n1
+
+
+def balanced_shards(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Deal pair indices to ``world`` ranks by longest-processing-time-first: heaviest remaining pair to the
+    currently lightest rank (ties: lower rank / lower index), with every rank holding ceil(B / world) pairs at
+    most so the gather buffer keeps its fixed shape.  Deterministic, identical on every rank."""
+    cap = (len(costs) + world - 1) // world
+    order = sorted(range(len(costs)), key=lambda i: (-float(costs[i]), i))
+    load, shards = [0.0] * world, [[] for _ in range(world)]
+    for i in order:
+        r = min((r for r in range(world) if len(shards[r]) < cap), key=lambda r: (load[r], r))
+        shards[r].append(i)
+        load[r] += float(costs[i])
+    return [sorted(sh) for sh in shards]
+
+
+def _take(data: dict, idx) -> dict:
+    """Rows `idx` (slice or index tensor) of every per-pair tensor of the nested input dict."""
+    pick = lambda t: t[idx] if isinstance(idx, slice) else t.index_select(0, idx.to(t.device))
+    return {k: ({kk: pick(vv) for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in data.items()}
 
 
 class PairShardedMatcher:
@@ -51,20 +77,37 @@ class PairShardedMatcher:
     def rank(self) -> int:
         return dist.get_rank(self.group) if dist.is_initialized() else 0
 
-    def forward(self, data: dict) -> Dict[str, torch.Tensor]:
+    def assignment(self, data: dict, balance: Optional[bool] = None) -> List[List[int]]:
+        """Pair indices per rank: contiguous blocks, or work-balanced when the batch is ragged (default) / on request."""
         batch = data["image0"]["keypoints"].shape[0]
-        lo, hi = shard_range(batch, self.rank, self.world)
-        return self.forward_local(_slice_data(data, lo, hi), batch)
+        num0, num1 = data["image0"].get("num_keypoints"), data["image1"].get("num_keypoints")
+        if balance is None:
+            balance = num0 is not None or num1 is not None
+        if not balance or self.world == 1:
+            return [list(range(*shard_range(batch, r, self.world))) for r in range(self.world)]
+        full0, full1 = data["image0"]["keypoints"].shape[1], data["image1"]["keypoints"].shape[1]
+        n0 = [full0] * batch if num0 is None else [int(v) for v in torch.as_tensor(num0).tolist()]
+        n1 = [full1] * batch if num1 is None else [int(v) for v in torch.as_tensor(num1).tolist()]
+        return balanced_shards([pair_cost(a, b) for a, b in zip(n0, n1)], self.world)
+
+    def forward(self, data: dict, balance: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+        batch = data["image0"]["keypoints"].shape[0]
+        shards = self.assignment(data, balance)
+        mine = shards[self.rank]
+        contiguous = all(sh == list(range(sh[0], sh[0] + len(sh))) for sh in shards if sh)
+        idx = slice(mine[0], mine[-1] + 1) if (mine and contiguous) else torch.tensor(mine, dtype=torch.long)
+        return self.forward_local(_take(data, idx), batch, shards)
 
     __call__ = forward
 
-    def forward_local(self, local: dict, global_batch: int) -> Dict[str, torch.Tensor]:
+    def forward_local(self, local: dict, global_batch: int, shards: Optional[List[List[int]]] = None) -> Dict[str, torch.Tensor]:
         m = local["image0"]["keypoints"].shape[1]
         n = local["image1"]["keypoints"].shape[1]
         world, rank = self.world, self.rank
-        lo, hi = shard_range(global_batch, rank, world)
-        nloc = hi - lo
-        assert local["image0"]["keypoints"].shape[0] == nloc, "local shard size does not match shard_range"
+        if shards is None:
+            shards = [list(range(*shard_range(global_batch, r, world))) for r in range(world)]
+        nloc = len(shards[rank])
+        assert local["image0"]["keypoints"].shape[0] == nloc, "local shard size does not match the pair assignment"
         dev = local["image0"]["keypoints"].device
         out = self.matcher(local) if nloc > 0 else None
         # ---- pack [pairs_max][2m + 2n + 1] int32: matches0 | bits(scores0) | matches1 | bits(scores1) | stop
@@ -88,11 +131,11 @@ class PairShardedMatcher:
             dist.all_gather_into_tensor(gathered, send, group=self.group)
             if via_host:
                 gathered = gathered.to(dev)
-            rows = []
-            for r in range(world):
-                rlo, rhi = shard_range(global_batch, r, world)
-                rows.append(gathered[r * per_rank: r * per_rank + (rhi - rlo)])
-            full = torch.cat(rows, 0)
+            # rank r's k-th row is pair shards[r][k]: one gather of rows puts the batch back in input order
+            src = torch.empty(global_batch, dtype=torch.long)
+            for r, sh in enumerate(shards):
+                src[torch.tensor(sh, dtype=torch.long)] = r * per_rank + torch.arange(len(sh))
+            full = gathered.index_select(0, src.to(gathered.device))
         else:
             full = buf[:nloc]
         m0 = full[:, 0:m].long()

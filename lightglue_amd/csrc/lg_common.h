@@ -132,6 +132,25 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
+// Cross-row exchanges without LDS (gfx950 v_permlane16_swap / v_permlane32_swap; __shfl_xor = ds_bpermute is an
+// LDS round trip).  With both operands = x: swap16 leaves {x.row0, x.row0, x.row2, x.row2} / {x.row1, x.row1, x.row3,
+// x.row3}, swap32 leaves {x.lo, x.lo} / {x.hi, x.hi} — combining the two halves IS the xor-16 / xor-32 reduction step.
+// (elements are copied to scalars before the bit_cast: __builtin_bit_cast on `r[1]` directly reads element 0 with this clang)
+struct SwapPair { float a, b; };
+__device__ __forceinline__ SwapPair swap16(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+    const unsigned lo = r[0], hi = r[1];
+    return {__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi)};
+}
+__device__ __forceinline__ SwapPair swap32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+    const unsigned lo = r[0], hi = r[1];
+    return {__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi)};
+}
+__device__ __forceinline__ float xor16_max(float x) { const SwapPair p = swap16(x); return fmaxf(p.a, p.b); }
+__device__ __forceinline__ float xor32_max(float x) { const SwapPair p = swap32(x); return fmaxf(p.a, p.b); }
+__device__ __forceinline__ float xor16_sum(float x) { const SwapPair p = swap16(x); return p.a + p.b; }
+__device__ __forceinline__ float xor32_sum(float x) { const SwapPair p = swap32(x); return p.a + p.b; }
 __device__ __forceinline__ float dpp_xor1(float v) { return dpp_mov<0xB1>(v); }   // quad_perm [1,0,3,2]
 __device__ __forceinline__ float dpp_xor2(float v) { return dpp_mov<0x4E>(v); }   // quad_perm [2,3,0,1]
 // sum over the 16 lanes of a DPP row (lanes sharing lane >> 4); every lane of the row gets the total

@@ -78,6 +78,7 @@ struct AttnArgs {
     float* ctx;       // [R][256] fp32, column = head*64 + d
     int R; int cross; // cross: segment s attends to segment s^1 (q and k both read from `q`)
     float scale_log2e;
+    long long* dbg;   // profiling builds (-DLG_ATTN_TIMING) only: [blocks][4 waves][8] phase clock sums
 };
 hipError_t launch_attention(int attn_prec, const AttnArgs& a, hipStream_t s);
 

@@ -125,11 +125,6 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
     };
 
     const int ntiles = (kvlen + ABK - 1) / ABK;
-#ifdef LG_ATTN_SETPRIO
-#define ATT_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define ATT_PRIO(x) do { } while (0)
-#endif
 #ifdef LG_ATTN_TIMING   // profiling build only (tools/attn_timing.py): per-phase s_memtime sums, wave-uniform
     long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
 #define ATT_TICK(slot) do { const long long _n = clock64(); tacc[slot] += _n - tprev; tprev = _n; } while (0)
@@ -151,7 +146,6 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
         f32x4 s[4][2];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) { s[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        ATT_PRIO(1);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
 #pragma unroll
@@ -161,7 +155,6 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
                 mma_chunk<Tag>(s[kt][1], kf, qf[1][c]);
             }
         }
-        ATT_PRIO(0);
         ATT_TICK(2);
         // ---- online softmax (fp32), per query column.  Only the last tile can hold dead keys.
         if (kv0 + ABK > kvlen) {   // wave-uniform
@@ -179,24 +172,17 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
             float mx = fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3]));
 #pragma unroll
             for (int kt = 1; kt < 4; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(s[kt][qt][0], s[kt][qt][1]), fmaxf(s[kt][qt][2], s[kt][qt][3])));
-#ifdef LG_ATTN_SHFL
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-#else
             mx = xor32_max(xor16_max(mx));   // the 4 lane groups of a query column, no LDS round trip
-#endif
             m_new[qt] = fmaxf(m_run[qt], mx * a.scale_log2e);   // finite: every tile holds >= 1 live key (scale > 0)
         }
         ATT_TICK(3);
-        // rescale the running output only when some row's maximum actually moved (exact: alpha == 1
-        // otherwise); keeps the O accumulators untouched by the VALU on most tiles
-#ifdef LG_ATTN_DEFER
-        // deferred rescale: keep the stale running maximum while no row's maximum grew by more than 2^LG_ATTN_DEFER
-        // (probabilities then reach at most 2^LG_ATTN_DEFER instead of 1: exact in fp32 l/O, harmless in f16/bf16 P)
-        if (__any((m_new[0] > m_run[0] + (float)LG_ATTN_DEFER) || (m_new[1] > m_run[1] + (float)LG_ATTN_DEFER))) {
-#else
-        if (__any((m_new[0] != m_run[0]) || (m_new[1] != m_run[1]))) {
-#endif
+        // Deferred rescale (guide T13): keep the stale running maximum while no row's maximum grew by more than
+        // DEFER_LOG2 (base-2 units) — probabilities then reach at most 2^8 instead of 1, which costs nothing in the fp32
+        // l / O accumulators and nothing relative in the f16 / bf16 P operand.  Order is the textbook one: decide,
+        // rescale o and l, THEN exponentiate this tile against the (possibly updated) maximum.  The first tile always
+        // takes the branch (m_run = -inf); on most later tiles the O accumulators are not touched by the VALU at all.
+        constexpr float DEFER_LOG2 = 8.f;
+        if (__any((m_new[0] > m_run[0] + DEFER_LOG2) || (m_new[1] > m_run[1] + DEFER_LOG2))) {
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new[qt]);
@@ -222,7 +208,6 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
         }
         ATT_TICK(4);
         // ---- O^T += V^T P^T
-        ATT_PRIO(1);
         if constexpr (EPC == 8) {
 #pragma unroll
             for (int tp = 0; tp < 2; ++tp) {
@@ -251,7 +236,6 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
                 }
             }
         }
-        ATT_PRIO(0);
         ATT_TICK(5);
     }
 #ifdef LG_ATTN_TIMING

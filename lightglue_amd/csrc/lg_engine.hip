@@ -94,7 +94,7 @@ struct lg_engine {
     size_t tail_cat_layer_bytes = 0, tail_2_layer_bytes = 0;
     char *w_sqkv_p = nullptr, *w_cqkv_p = nullptr;   // fragment-packed projection weights (lg_proj.hip)
     size_t sqkv_layer_bytes = 0, cqkv_layer_bytes = 0;
-    int fused_tail = 1, fused_proj = 1, tail_variant = 0;   // 0 = lg_tail.hip (64 rows, LDS-resident), 1 = 4 waves x 64 rows, 2 = 8 waves x 128 rows
+    int fused_tail = 1, fused_proj = 1, fused_next = 1, tail_variant = 0;   // 0 = lg_tail.hip (64 rows, LDS-resident), 1 = 4 waves x 64 rows, 2 = 8 waves x 128 rows
     int tail_timing = 0; long long* TAILDBG = nullptr;
     // ---- workspace
     void* ws = nullptr; size_t ws_bytes = 0;
@@ -499,6 +499,7 @@ int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
     if (std::strcmp(key, "fused_tail") == 0) { e->fused_tail = value != 0; return LG_OK; }
     if (std::strcmp(key, "tail_variant") == 0) { e->tail_variant = value; return LG_OK; }
     if (std::strcmp(key, "fused_proj") == 0) { e->fused_proj = value != 0; return LG_OK; }
+    if (std::strcmp(key, "fused_next") == 0) { e->fused_next = value != 0; return LG_OK; }
     if (std::strcmp(key, "tail_timing") == 0) { e->tail_timing = value; return LG_OK; }   // 1: tail kernel, 2: self projection, 3: self attention (LG_ATTN_TIMING builds)
     return fail(LG_ERR_INVALID, std::string("unknown option '") + key + "'");
 }
@@ -601,19 +602,32 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
     STEP_DONE();
     const float scale_log2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
 
+    auto make_proj = [&](int layer, int blk) {   // q/k/v projection of block `blk` of `layer` (lg_proj.hip / fused into lg_tail.hip)
+        ProjArgs pj{};
+        pj.rs = rs_act; pj.X = e->X; pj.R = R; pj.q = e->Q; pj.k = e->K; pj.vt = e->VT;
+        pj.W = blk == 0 ? e->w_sqkv_p + (size_t)layer * e->sqkv_layer_bytes : e->w_cqkv_p + (size_t)layer * e->cqkv_layer_bytes;
+        pj.bias = blk == 0 ? e->b_sqkv + (size_t)layer * 768 : e->b_cqkv + (size_t)layer * 512;
+        pj.Nout = blk == 0 ? 768 : 512; pj.n_qk_groups = blk == 0 ? 2 : 1;
+        pj.cosb = blk == 0 ? e->COS : nullptr; pj.sinb = blk == 0 ? e->SIN : nullptr;
+        pj.dbg = nullptr;
+        return pj;
+    };
+    // fused_next: a tail kernel also runs the NEXT block's projection on the x tile it has just produced.  Across a
+    // layer boundary that is only valid when nothing re-orders rows in between (no early stop / pruning step).
+    const bool fuse_next = e->fused_next && e->fused_tail && e->fused_proj && e->tail_variant == 0 && e->tail_timing == 0 &&
+                           e->debug_stop < 0 && launch_tail_supports_next(prec, ap);
+    bool proj_done = false;
     for (int i = 0; i < L; ++i) {
         for (int blk = 0; blk < 2; ++blk) {  // 0 = SelfBlock (ref :159-172), 1 = CrossBlock (ref :201-230)
             if (e->fused_proj) {
-                ProjArgs pj{};
-                pj.rs = rs_act; pj.X = e->X; pj.R = R; pj.q = e->Q; pj.k = e->K; pj.vt = e->VT;
-                pj.W = blk == 0 ? e->w_sqkv_p + (size_t)i * e->sqkv_layer_bytes : e->w_cqkv_p + (size_t)i * e->cqkv_layer_bytes;
-                pj.bias = blk == 0 ? e->b_sqkv + (size_t)i * 768 : e->b_cqkv + (size_t)i * 512;
-                pj.Nout = blk == 0 ? 768 : 512; pj.n_qk_groups = blk == 0 ? 2 : 1;
-                pj.cosb = blk == 0 ? e->COS : nullptr; pj.sinb = blk == 0 ? e->SIN : nullptr;
-                pj.dbg = (e->tail_timing == 2 && blk == 0) ? e->TAILDBG : nullptr;
-                TRY(prof_begin(e, blk == 0 ? PC_GEMM_QKV_SELF : PC_GEMM_QKV_CROSS, s));
-                HIPCHK(launch_proj(prec, ap, pj, s));
-                TRY(prof_end(e, s));
+                if (!proj_done) {   // otherwise the previous block's tail kernel has already produced q/k/v (fused_next)
+                    ProjArgs pj = make_proj(i, blk);
+                    pj.dbg = (e->tail_timing == 2 && blk == 0) ? e->TAILDBG : nullptr;
+                    TRY(prof_begin(e, blk == 0 ? PC_GEMM_QKV_SELF : PC_GEMM_QKV_CROSS, s));
+                    HIPCHK(launch_proj(prec, ap, pj, s));
+                    TRY(prof_end(e, s));
+                }
+                proj_done = false;
             } else
             {
                 GemmArgs g = blk == 0 ? gemm(EPI_QKV, rs_act, e->X, D, nullptr, 0, D, D, woff(e->w_sqkv, (size_t)i * 768 * D), e->b_sqkv + (size_t)i * 768, 768, nullptr, 0, 1.f)
@@ -643,8 +657,12 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 ta.W2 = (blk ? e->w_ctail_2 : e->w_stail_2) + (size_t)i * e->tail_2_layer_bytes;
                 ta.b2 = (blk ? e->b_cf2 : e->b_sf2) + (size_t)i * D;
                 ta.dbg = e->tail_timing == 1 ? e->TAILDBG : nullptr;
+                if (fuse_next && (blk == 0 || (i + 1 < L && !do_stop && !do_prune))) {
+                    ta.next = blk == 0 ? make_proj(i, 1) : make_proj(i + 1, 0);
+                    proj_done = true;
+                }
                 TRY(prof_begin(e, PC_TAIL, s));
-                HIPCHK(e->tail_variant == 1 ? launch_tail4(prec, ta, s) : e->tail_variant == 2 ? launch_tail128(prec, ta, s) : launch_tail(prec, ta, s));
+                HIPCHK(e->tail_variant == 1 ? launch_tail4(prec, ta, s) : e->tail_variant == 2 ? launch_tail128(prec, ta, s) : launch_tail(prec, ap, ta, s));
                 TRY(prof_end(e, s));
                 STEP_DONE(); STEP_DONE(); STEP_DONE(); STEP_DONE();
                 continue;

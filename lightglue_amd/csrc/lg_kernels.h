@@ -41,22 +41,6 @@ struct SimArgs {
 };
 hipError_t launch_sim(int prec, const SimArgs& a, hipStream_t s);
 
-// ---------------------------------------------------------------- fused block tail (lg_tail.hip)
-// x <- x + ffn(cat[x, out_proj(ctx)]) with out_proj folded into ffn.0 on the host (see lg_tail.hip).
-// Weights are packed in MFMA-fragment order: plane p (hi, lo) at element offset p*rows*512, and within a
-// plane element ((nt*NKC + kc)*64 + lane)*EPC + j = W[nt*16 + (lane&15)][kc*4*EPC + (lane>>4)*EPC + j].
-struct TailArgs {
-    RowSpace rs;
-    float* X; const float* CTX;
-    const void* Wcat; const float* bcat;     // [512][512] fragment-packed, [512]
-    const float* gamma; const float* beta;   // LayerNorm(512)
-    const void* W2; const float* b2;         // [256][512] fragment-packed, [256]
-    long long* dbg;                          // profiling tap: [blocks][8 waves][8] shader-clock stamps, or nullptr
-};
-hipError_t launch_tail(int prec, const TailArgs& a, hipStream_t s);    // 8 waves, one workgroup per CU (lg_tail.hip)
-hipError_t launch_tail4(int prec, const TailArgs& a, hipStream_t s);   // 4 waves x 64 rows, two workgroups per CU (lg_tail4.hip)
-hipError_t launch_tail128(int prec, const TailArgs& a, hipStream_t s); // 8 waves x 128 rows: half the weight stream per row (lg_tail4.hip)
-
 // ---------------------------------------------------------------- attention input projections (lg_proj.hip)
 // q/k/v (self, rotary on q,k) or qk/v (cross) from the residual stream; weights fragment-packed like TailArgs
 // ([Nout][256], columns ordered [group][head][64], hi plane then lo plane).
@@ -70,6 +54,26 @@ struct ProjArgs {
     long long* dbg;                                  // profiling tap: [blocks][8 waves][8] shader-clock stamps, or nullptr
 };
 hipError_t launch_proj(int prec, int attn_prec, const ProjArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- fused block tail (lg_tail.hip)
+// x <- x + ffn(cat[x, out_proj(ctx)]) with out_proj folded into ffn.0 on the host (see lg_tail.hip).
+// Weights are packed in MFMA-fragment order: plane p (hi, lo) at element offset p*rows*512, and within a
+// plane element ((nt*NKC + kc)*64 + lane)*EPC + j = W[nt*16 + (lane&15)][kc*4*EPC + (lane>>4)*EPC + j].
+struct TailArgs {
+    RowSpace rs;
+    float* X; const float* CTX;
+    const void* Wcat; const float* bcat;     // [512][512] fragment-packed, [512]
+    const float* gamma; const float* beta;   // LayerNorm(512)
+    const void* W2; const float* b2;         // [256][512] fragment-packed, [256]
+    long long* dbg;                          // profiling tap: [blocks][8 waves][8] shader-clock stamps, or nullptr
+    // optional: the NEXT block's q/k/v projection, run on the x tile this kernel has just produced (next.W == nullptr:
+    // none).  next.X is unused; supported for 16-bit operand / attention precisions (launch_tail_supports_next).
+    ProjArgs next;
+};
+bool launch_tail_supports_next(int prec, int attn_prec);
+hipError_t launch_tail(int prec, int attn_prec, const TailArgs& a, hipStream_t s);    // 8 waves, one workgroup per CU (lg_tail.hip)
+hipError_t launch_tail4(int prec, const TailArgs& a, hipStream_t s);   // 4 waves x 64 rows, two workgroups per CU (lg_tail4.hip)
+hipError_t launch_tail128(int prec, const TailArgs& a, hipStream_t s); // 8 waves x 128 rows: half the weight stream per row (lg_tail4.hip)
 
 // ---------------------------------------------------------------- attention (lg_attention.hip)
 struct AttnArgs {

@@ -25,7 +25,10 @@
 //            (Running the two halves of the workgroup in opposite MFMA/GELU order to overlap the pipes was
 //            measured and lost 8k cycles per workgroup; see DESIGN.md.)
 //   epilogue out tile staged through LDS, residual add and store as full 1 KB rows
-#include "lg_kernels.h"
+//   next     (optional, NEXT != 0) the new x tile is ALSO written to LDS in operand precision and the NEXT block's
+//            q/k/v projection (lg_proj_body.h; SelfBlock -> this layer's CrossBlock, CrossBlock -> next layer's
+//            SelfBlock) runs here: saves that kernel's launch, its x-tile read + conversion and one grid drain.
+#include "lg_proj_body.h"
 
 namespace lg {
 
@@ -86,7 +89,12 @@ __device__ __forceinline__ void tail_mma(f32x4& acc, const u32x4* a, const u32x4
     }
 }
 
-template <int PREC>
+constexpr int OT_LD = 260;                       // padded row stride (floats) of the staged fp32 output tile
+constexpr int OT_BYTES = TBM * OT_LD * 4;        // 66 560
+
+// NEXT: 0 = plain tail, 1 = + SelfBlock projection of the next layer (768 columns, rotary), 2 = + CrossBlock
+// projection (512 columns).  TA = element type of q/k/v (attention operand precision), only read when NEXT != 0.
+template <int PREC, int NEXT, class TA>
 __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     typedef typename TT<PREC>::Tag Tag;
     constexpr int EPC = Tag::EPC, KE = TT<PREC>::KE, NPART = TT<PREC>::NPART;
@@ -357,10 +365,18 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         const int c = tid + TTHREADS * i, row = c >> 6, c4 = c & 63;
         xres[i] = *reinterpret_cast<const f32x4*>(a.X + (long long)(t.grow0 + row) * 256 + c4 * 4);
     }
+    // NEXT: rotary tables of the tile for the next projection (registers now, LDS after the g tiles are dead)
+    f32x4 ropec = {0.f, 0.f, 0.f, 0.f}, ropes = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (NEXT == 1) {
+        ropec = *reinterpret_cast<const f32x4*>(a.next.cosb + (long long)t.grow0 * 32 + tid * 4);
+        ropes = *reinterpret_cast<const f32x4*>(a.next.sinb + (long long)t.grow0 * 32 + tid * 4);
+    }
+    char* smA = smem + OT_BYTES;                                   // next projection: activation tile (operand precision)
+    float* smCS = reinterpret_cast<float*>(smA + PJL<PREC>::A_BYTES);   //                  rotary tables
     __syncthreads();   // g tiles are dead; reuse the region as a [64][256+4] fp32 output tile
     {
         float* ot = reinterpret_cast<float*>(smem);
-        constexpr int OLD = 260;   // padded row stride (floats): rows 4g+r land on different banks
+        constexpr int OLD = OT_LD;   // padded row stride (floats): rows 4g+r land on different banks
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int col = w * 32 + nt * 16 + lr;
@@ -374,31 +390,67 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {     // 64 rows x 64 float4 = 4096 chunks, 8 per thread; a wave covers one full row
             const int c = tid + TTHREADS * i, row = c >> 6, c4 = c & 63;
-            if (t.r0 + row < qlen) {
-                const f32x4 d = *reinterpret_cast<const f32x4*>(ot + row * OLD + c4 * 4);
-                *reinterpret_cast<f32x4*>(a.X + (long long)(t.grow0 + row) * 256 + c4 * 4) = xres[i] + d;
+            const f32x4 d = *reinterpret_cast<const f32x4*>(ot + row * OLD + c4 * 4);
+            const f32x4 xn = xres[i] + d;
+            if (t.r0 + row < qlen) *reinterpret_cast<f32x4*>(a.X + (long long)(t.grow0 + row) * 256 + c4 * 4) = xn;
+            if constexpr (NEXT != 0) {   // the same 4 columns, in operand precision, into the projection's A tile
+                static_assert(EPC == 8, "fused next projection: 16-bit operands only");
+                const int col = c4 * 4;
+                char* dst = smA + (col >> 6) * PJL<PREC>::TILE + lds_off<128>(row, (col & 63) >> 3) + (col & 7) * 2;
+                if constexpr (PREC == PREC_BF16X3) {
+                    const float h0 = bf16_round(xn[0]), h1 = bf16_round(xn[1]), h2 = bf16_round(xn[2]), h3 = bf16_round(xn[3]);
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{pack2_bf16(h0, h1), pack2_bf16(h2, h3)};
+                    *reinterpret_cast<u32x2*>(dst + PJL<PREC>::A_PLANE) = u32x2{pack2_bf16(xn[0] - h0, xn[1] - h1), pack2_bf16(xn[2] - h2, xn[3] - h3)};
+                } else {
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<Tag>(xn[0], xn[1]), pack2<Tag>(xn[2], xn[3])};
+                }
             }
         }
     }
     stamp(5);
+    if constexpr (NEXT != 0) {
+        if constexpr (NEXT == 1) {
+            *reinterpret_cast<f32x4*>(smCS + tid * 4) = ropec;
+            *reinterpret_cast<f32x4*>(smCS + 2048 + tid * 4) = ropes;
+        }
+        // staging of the projection outputs aliases the fp32 output tile: every thread is past its reads of it when it
+        // reaches the barrier inside proj_compute, and the staging is first written after that barrier
+        proj_compute<PREC, TA, NEXT == 1 ? 3 : 2, 2>(a.next, t, smA, smem, smCS, 8);
+    }
 }
 
-template <int PREC> static hipError_t launch_tail_prec(const TailArgs& a, hipStream_t s) {
+template <int PREC, int NEXT, class TA> static hipError_t launch_tail_t(const TailArgs& a, hipStream_t s) {
     const int R = a.rs.B * (a.rs.cap0 + a.rs.cap1);
-    auto kern = tail_kernel<PREC>;
-    constexpr int smem = TL<PREC>::TOTAL > 64 * 260 * 4 ? TL<PREC>::TOTAL : 64 * 260 * 4;
+    auto kern = tail_kernel<PREC, NEXT, TA>;
+    constexpr int base = TL<PREC>::TOTAL > OT_BYTES ? TL<PREC>::TOTAL : OT_BYTES;
+    constexpr int fused = OT_BYTES + PJL<PREC>::A_BYTES + PJ_CS_BYTES;
+    constexpr int smem = (NEXT != 0 && fused > base) ? fused : base;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(R / TBM), dim3(TTHREADS), smem, s, a);
     return hipGetLastError();
 }
+template <int PREC, class TA> static hipError_t launch_tail_next(const TailArgs& a, hipStream_t s) {
+    if (!a.next.W) return launch_tail_t<PREC, 0, TA>(a, s);
+    static_assert(PJO<TA, 3>::O_BYTES <= OT_BYTES, "projection staging must fit the dead output tile");
+    if (a.next.Nout == 768 && a.next.cosb) return launch_tail_t<PREC, 1, TA>(a, s);
+    if (a.next.Nout == 512 && !a.next.cosb) return launch_tail_t<PREC, 2, TA>(a, s);
+    return hipErrorInvalidValue;
+}
 
-hipError_t launch_tail(int prec, const TailArgs& a, hipStream_t s) {
+// the fused next projection exists for the 16-bit operand / attention combinations the engine runs by default
+bool launch_tail_supports_next(int prec, int attn_prec) {
+    return (prec == PREC_BF16X3 && attn_prec == PREC_F16) || (prec == PREC_BF16 && attn_prec == PREC_BF16) ||
+           (prec == PREC_F16 && attn_prec == PREC_F16);
+}
+
+hipError_t launch_tail(int prec, int attn_prec, const TailArgs& a, hipStream_t s) {
+    if (a.next.W && !launch_tail_supports_next(prec, attn_prec)) return hipErrorInvalidValue;
     switch (prec) {
-        case PREC_F32: return launch_tail_prec<PREC_F32>(a, s);
-        case PREC_BF16: return launch_tail_prec<PREC_BF16>(a, s);
-        case PREC_F16: return launch_tail_prec<PREC_F16>(a, s);
-        case PREC_BF16X3: return launch_tail_prec<PREC_BF16X3>(a, s);
+        case PREC_F32: return launch_tail_t<PREC_F32, 0, float>(a, s);
+        case PREC_BF16: return launch_tail_next<PREC_BF16, bf16_t>(a, s);
+        case PREC_F16: return launch_tail_next<PREC_F16, f16_t>(a, s);
+        case PREC_BF16X3: return launch_tail_next<PREC_BF16X3, f16_t>(a, s);
     }
     return hipErrorInvalidValue;
 }

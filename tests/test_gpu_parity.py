@@ -238,6 +238,51 @@ def test_full_log_assignment_output(adaptive):
         assert la[b][333, 290] == 0.0
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16x3", 5e-2)])
+def test_attention_deferred_rescale_with_sharp_logits(precision, tol):
+    """The attention kernel rescales its running output only when a row's maximum grows by more than 2^8 (deferred
+    rescale).  Random weights never exercise that branch after the first tile, so sharpen layer 0's logits (Wqkv x 60:
+    base-2 logit spread ~7): the oracle's own q/k must then show BOTH rows whose maximum jumps past the threshold in a later
+    64-key tile and rows that stay below it, and the attention context must still match the oracle."""
+    require_gpu()
+    sd = synth.make_state_dict(0, recipe="A")
+    sd = {k: v.copy() for k, v in sd.items()}
+    sd["transformers.0.self_attn.Wqkv.weight"] *= 60.0
+    data = synth.make_batch(5, 1, 320, 280)
+    conf_kw = dict(depth_confidence=-1, width_confidence=-1)
+    tr = {"_full_layers": (0,)}
+    d0, d1 = data["image0"], data["image1"]
+    O.forward_pair(sd, O.make_conf(**conf_kw), d0["keypoints"][0], d1["keypoints"][0], d0["descriptors"][0], d1["descriptors"][0],
+                   d0["image_size"][0], d1["image_size"][0], trace=tr)
+    q, k = tr["l0_self0_q"], tr["l0_self0_k"]                       # [H, n, 64]
+    logits2 = np.einsum("hqd,hkd->hqk", q, k) * 0.125 * 1.4426950408889634   # base-2 units, as the kernel sees them
+    tile_max = np.stack([logits2[:, :, i:i + 64].max(-1) for i in range(0, logits2.shape[-1], 64)], -1)
+    run = np.maximum.accumulate(tile_max, -1)
+    jumps = tile_max[..., 1:] - run[..., :-1]
+    assert (jumps > 8).any() and ((jumps > 0) & (jumps <= 8)).any(), "fixture must exercise both sides of the threshold"
+    res = gpu_util.stage_errors(sd, data, precision, conf_kw, fused=True)
+    assert res["self.attn_ctx"][1] <= tol, res["self.attn_ctx"]
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+def test_fused_next_projection_is_bit_identical(precision):
+    """The tail kernel runs the next block's q/k/v projection on the x tile it has just produced (engine option
+    fused_next, default on): same arithmetic on the same fp32 values as the standalone projection kernel, so every
+    output must be BIT-identical with the option off — non-adaptive (both block boundaries fused) and adaptive
+    (only SelfBlock -> CrossBlock fused, rows move between layers)."""
+    require_gpu()
+    for recipe, kw in (("A", dict(depth_confidence=-1, width_confidence=-1)), ("B", dict(pruning_min_kpts=64))):
+        sd = synth.make_state_dict(0, recipe=recipe)
+        data = gpu_util.to_torch(synth.make_batch(17, 3, 300, 333))
+        model = gpu_util.make_model(sd, precision, **kw)
+        fused = model(data)
+        model.set_option("fused_next", 0)
+        plain = model(data)
+        for key in ("matches0", "matches1", "matching_scores0", "matching_scores1", "prune0", "prune1"):
+            assert torch.equal(fused[key], plain[key]), (recipe, key)
+        assert torch.equal(torch.as_tensor(fused["stop"]), torch.as_tensor(plain["stop"]))
+
+
 @pytest.mark.parametrize("variant", [1, 2])
 def test_streaming_tail_variants_match_golden(variant):
     """lg_tail4.hip: <4 waves x 64 rows> and <8 waves x 128 rows> decompositions of the fused tail (engine option

@@ -63,7 +63,11 @@ def flops_per_launch(pairs: int, n: int, m: int):
 
 # HBM bytes per launch of the dominant kernel measured with rocprofv3 PMC passes (FETCH_SIZE x 2 per the gfx950
 # correction in MI355X_MICROARCH.md + WRITE_SIZE), profiles/r01b_pmc_{fetch,write}.md; valid for the default workload only.
-PMC_TRAFFIC_BYTES = {("bf16x3", 32, 1024, "fused_tail"): (2 * 1.199e5 + 6.554e4) * 1024}
+# "+next": the tail kernel that also runs the next block's projection (profiles/r01e_pmc_{fetch,write}.md): average over
+# the 8 launches with a SelfBlock projection, the 9 with a CrossBlock projection and the last, plain one.
+PMC_TRAFFIC_BYTES = {("bf16x3", 32, 1024, "fused_tail"): (2 * 1.199e5 + 6.554e4) * 1024,
+                     ("bf16x3", 32, 1024, "fused_tail+next"): (8 * (2 * 1.433e5 + 1.638e5) + 9 * (2 * 1.276e5 + 1.311e5)
+                                                               + (2 * 1.199e5 + 6.554e4)) / 18 * 1024}
 
 
 def hbm_bytes_assign(pairs: int, n: int, m: int) -> float:

@@ -298,7 +298,11 @@ class LightGlue(nn.Module):
         b, m, _ = kpts0.shape
         b, n, _ = kpts1.shape
         conf = self.conf
-        f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+        def f32(t):   # only the data pointer is handed on: tensors that already qualify pass through untouched
+            if t.dtype is torch.float32 and t.device == device and t.is_contiguous():
+                return t
+            return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
         k0, k1 = f32(kpts0), f32(kpts1)
         desc0, desc1 = f32(d0["descriptors"]), f32(d1["descriptors"])
         assert desc0.shape[-1] == conf.input_dim
@@ -332,18 +336,26 @@ class LightGlue(nn.Module):
         do_compile = bool(self.static_lengths) and max(m, n) <= max(self.static_lengths)
         do_point_pruning = conf.width_confidence > 0 and not do_compile
 
-        i32 = dict(device=device, dtype=torch.int32)
-        m0 = torch.empty((b, m), **i32)
-        m1 = torch.empty((b, n), **i32)
-        ms0 = torch.empty((b, m), device=device, dtype=torch.float32)
-        ms1 = torch.empty((b, n), device=device, dtype=torch.float32)
-        stop = torch.empty((b,), **i32)
+        # ---- outputs: ONE int32 and ONE fp32 allocation, carved into the tensors of the C ABI (16-byte aligned pieces);
+        # the int32 block is widened to int64 by a single kernel after the forward (ref dtypes :619-629)
         kmax = min(m, n)
-        mlist = torch.empty((b, kmax, 2), **i32)
-        mscore_list = torch.empty((b, kmax), device=device, dtype=torch.float32)
-        n_matches = torch.empty((b,), **i32)
-        prune0 = torch.empty((b, m), **i32) if do_point_pruning else None
-        prune1 = torch.empty((b, n), **i32) if do_point_pruning else None
+        r4 = lambda x: (x + 3) & ~3
+        isz = [b * m, b * n, b * kmax * 2, b * m if do_point_pruning else 0, b * n if do_point_pruning else 0, 2 * b]
+        ioff = [0]
+        for x in isz:
+            ioff.append(ioff[-1] + r4(x))
+        ibuf = torch.empty((ioff[-1],), device=device, dtype=torch.int32)
+        fsz = [b * m, b * n, b * kmax]
+        foff = [0, r4(fsz[0]), r4(fsz[0]) + r4(fsz[1])]
+        fbuf = torch.empty((foff[2] + r4(fsz[2]),), device=device, dtype=torch.float32)
+        ipiece = lambda buf, k, *shape: buf[ioff[k]: ioff[k] + isz[k]].view(*shape)
+        m0, m1, mlist = ipiece(ibuf, 0, b, m), ipiece(ibuf, 1, b, n), ipiece(ibuf, 2, b, kmax, 2)
+        prune0 = ipiece(ibuf, 3, b, m) if do_point_pruning else None
+        prune1 = ipiece(ibuf, 4, b, n) if do_point_pruning else None
+        stop_nm = ipiece(ibuf, 5, 2, b)                     # [0] = stop, [1] = n_matches
+        ms0 = fbuf[foff[0]: foff[0] + fsz[0]].view(b, m)
+        ms1 = fbuf[foff[1]: foff[1] + fsz[1]].view(b, n)
+        mscore_list = fbuf[foff[2]: foff[2] + fsz[2]].view(b, kmax)
 
         log_assignment = None
         if self.return_log_assignment and m > 0 and n > 0:
@@ -355,8 +367,8 @@ class LightGlue(nn.Module):
             b, m, n, 0 if do_point_pruning or conf.width_confidence <= 0 else _cabi.LG_FLAG_NO_PRUNING,
             ptr(k0), ptr(k1), ptr(desc0), ptr(desc1), ptr(size0), ptr(size1),
             ptr(extra[0]), ptr(extra[1]), ptr(extra[2]), ptr(extra[3]),
-            ptr(m0), ptr(m1), ptr(ms0), ptr(ms1), stop.data_ptr(), ptr(prune0), ptr(prune1),
-            ptr(mlist), ptr(mscore_list), n_matches.data_ptr(), ptr(num0), ptr(num1), ptr(log_assignment))
+            ptr(m0), ptr(m1), ptr(ms0), ptr(ms1), stop_nm[0].data_ptr(), ptr(prune0), ptr(prune1),
+            ptr(mlist), ptr(mscore_list), stop_nm[1].data_ptr(), ptr(num0), ptr(num1), ptr(log_assignment))
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             _cabi.check(_cabi.load().lg_engine_forward(handle, C.byref(io), C.c_void_p(stream)))
@@ -366,24 +378,26 @@ class LightGlue(nn.Module):
             return None
         # ---- output assembly (ref :593-629).  Everything that does not need the ragged sizes is enqueued BEFORE
         # the one host synchronisation of the forward, so the GPU is never idle waiting for Python.
-        m0_64, m1_64, mlist64 = m0.long(), m1.long(), mlist.long()
+        i64 = ibuf.long()
+        m0_64, m1_64, mlist64 = ipiece(i64, 0, b, m), ipiece(i64, 1, b, n), ipiece(i64, 2, b, kmax, 2)
         if do_point_pruning:
-            prune0, prune1 = prune0.long(), prune1.long()
+            prune0, prune1 = ipiece(i64, 3, b, m), ipiece(i64, 4, b, n)
         else:  # ref :616-617
-            prune0 = torch.full_like(ms0, float(conf.n_layers))
-            prune1 = torch.full_like(ms1, float(conf.n_layers))
+            pf = torch.full((b * (m + n),), float(conf.n_layers), device=device, dtype=torch.float32)
+            prune0, prune1 = pf[: b * m].view(b, m), pf[b * m:].view(b, n)
             if num0 is not None:
                 prune0 = prune0 * (torch.arange(m, device=device)[None] < num0[:, None])
             if num1 is not None:
                 prune1 = prune1 * (torch.arange(n, device=device)[None] < num1[:, None])
-        stop64 = stop.long() if b > 1 else None
-        counts = n_matches.tolist()  # host sync: the ragged lists need their sizes
-        matches = [mlist64[k, : counts[k]] for k in range(b)]
-        mscores = [mscore_list[k, : counts[k]] for k in range(b)]
+        stop64 = ipiece(i64, 5, 2, b)[0]
+        host = stop_nm.tolist()  # THE host sync of the forward: the ragged lists need their sizes (and B = 1 its `stop`)
+        counts = host[1]
+        matches = [row[:c] for row, c in zip(mlist64.unbind(0), counts)]
+        mscores = [row[:c] for row, c in zip(mscore_list.unbind(0), counts)]
         if not do_early_stop and m > 0 and n > 0 and not ragged:
             stop_out = conf.n_layers if b == 1 else torch.full((b,), conf.n_layers, device=device, dtype=torch.long)
         else:
-            stop_out = int(stop[0].item()) if b == 1 else stop64
+            stop_out = int(host[0][0]) if b == 1 else stop64
         extra_out = {} if log_assignment is None else {"log_assignment": log_assignment}
         return {
             **extra_out,

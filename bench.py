@@ -170,9 +170,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    # Per-class kernel times (HIP events around every launch) are taken over the WARM-UP steps; in the timed region only
+    # the dominant class keeps its events (the roofline leg needs exactly that kernel's launch duration, live), so the
+    # headline is not taxed by ~90 event records per step.  With --warmup < 2 everything is timed in the timed region.
+    warm_prof = {}
+    dom_class = None
+    if args.warmup >= 2:
         out = step()
-    model.profile(True, dev)
+        model.profile(True, dev)
+        for _ in range(args.warmup - 1):
+            out = step()
+        torch.cuda.synchronize(dev)
+        warm_prof = {k: (v[0] / (args.warmup - 1), v[1] / (args.warmup - 1)) for k, v in model.profile_read(dev).items() if v[1] > 0}
+        model.profile(False, dev)
+        fl0 = flops_per_launch(B, n, m)
+        dom_class = max((k for k in warm_prof if k in fl0), key=lambda k: warm_prof[k][0])
+    else:
+        for _ in range(args.warmup):
+            out = step()
+    model.profile(True, dev, only=dom_class)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -193,7 +209,8 @@ def main():
         value = total_pairs / dt
         fl = flops_per_launch(B, n, m)
         timed = {k: v for k, v in prof.items() if v[1] > 0}
-        fused_next = "fused_tail" in timed and "gemm_qkv_cross" not in timed
+        classes_seen = set(timed) | set(warm_prof)
+        fused_next = "fused_tail" in classes_seen and "gemm_qkv_cross" not in classes_seen
         if fused_next:
             # the tail kernel also runs the NEXT block's q/k/v projection (L cross + L-1 self projections over 2L tail
             # launches per forward): charge their algorithmic FLOPs to the launches that execute them
@@ -202,7 +219,12 @@ def main():
         dom_ms = timed[dom][0] / timed[dom][1]
         achieved = fl[dom] / (dom_ms * 1e-3) / 1e12
         peak = 157.3 if args.precision == "fp32" else 2500.0  # dense MFMA peak, MI355X_MICROARCH.md
-        kernel_ms = {k: round(v[0] / args.steps, 4) for k, v in timed.items()}
+        if warm_prof:   # per-class table from the warm-up steps; the dominant class from the timed region
+            kernel_ms = {k: round(v[0], 4) for k, v in warm_prof.items()}
+            kernel_ms[dom] = round(timed[dom][0] / args.steps, 4)
+            timed = {**{k: (v[0] * args.steps, v[1] * args.steps) for k, v in warm_prof.items()}, dom: timed[dom]}
+        else:
+            kernel_ms = {k: round(v[0] / args.steps, 4) for k, v in timed.items()}
         res = {
             "metric": "image-pairs/s at N=M=1024, 9 layers; match-index parity vs ref",
             "value": value,
@@ -230,6 +252,8 @@ def main():
                               "frac": hbm_bytes_assign(B, n, m) / (timed["assign"][0] / timed["assign"][1] * 1e-3) / 1e9 / 8000.0,
                               "algorithmic_bytes_per_launch": hbm_bytes_assign(B, n, m)} if "assign" in timed else None),
             "kernel_ms_per_step": kernel_ms,
+            "kernel_ms_per_step_source": ("HIP events around every launch during the warm-up steps; the roofline kernel's entry and "
+                                          "avg_launch_ms come from events inside the timed region") if warm_prof else "HIP events inside the timed region",
             "gpu_ms_per_step_sum": round(sum(kernel_ms.values()), 3),
             "algorithmic_tflops": value * flops_per_pair(n, m) / 1e12,
             "matches_per_pair": float(np.mean([(o > -1).sum().item() for o in out["matches0"]])) if "matches0" in out else None,

@@ -110,7 +110,8 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream);
  * (lg_tail.hip); "fused_proj" (default 1): the full-width q/k/v projection kernel (lg_proj.hip).  0 selects the
  * generic per-op GEMM kernels (kept for stage-by-stage parity tests).  "fused_next" (default 1): the tail kernel also
  * runs the NEXT block's q/k/v projection on the x tile it has just produced (bit-identical to the separate kernel;
- * needs fused_tail and fused_proj, 16-bit operand precisions). */
+ * needs fused_tail and fused_proj, 16-bit operand precisions).  "profile_only" (default -1): restrict the HIP-event
+ * timing of lg_engine_profile_enable to one kernel class (index of lg_profile_class_name), -1 = all classes. */
 int lg_engine_set_option(lg_engine* e, const char* key, int32_t value);
 
 /* ---- test / profiling taps (not used by the product path) ---- */

@@ -107,7 +107,8 @@ struct lg_engine {
     int *IND, *DST, *LEN, *LEN_ORIG, *LEN_OLD, *ACTIVE, *FINAL_LAYER, *ARG0, *ARG1;
     int debug_stop = -1;
     // ---- per-kernel-class HIP-event timing (bench.py roofline leg)
-    bool profiling = false;
+    bool profiling = false, prof_open = false;
+    int prof_only = -1;                // kernel class to time alone, -1 = every class
     struct ProfSpan { hipEvent_t a, b; int cls; };
     std::vector<ProfSpan> prof_pool;   // events, reused
     size_t prof_used = 0;
@@ -252,7 +253,8 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
 }
 
 int prof_begin(lg_engine* e, int cls, hipStream_t s) {
-    if (!e->profiling) return LG_OK;
+    e->prof_open = e->profiling && (e->prof_only < 0 || e->prof_only == cls);   // "profile_only": time one class, leave the rest unbracketed
+    if (!e->prof_open) return LG_OK;
     if (e->prof_used == e->prof_pool.size()) {
         lg_engine::ProfSpan sp{};
         HIPCHK(hipEventCreate(&sp.a)); HIPCHK(hipEventCreate(&sp.b));
@@ -263,7 +265,8 @@ int prof_begin(lg_engine* e, int cls, hipStream_t s) {
     return LG_OK;
 }
 int prof_end(lg_engine* e, hipStream_t s) {
-    if (!e->profiling) return LG_OK;
+    if (!e->prof_open) return LG_OK;
+    e->prof_open = false;
     HIPCHK(hipEventRecord(e->prof_pool[e->prof_used].b, s));
     e->prof_used++;
     return LG_OK;
@@ -500,6 +503,7 @@ int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
     if (std::strcmp(key, "tail_variant") == 0) { e->tail_variant = value; return LG_OK; }
     if (std::strcmp(key, "fused_proj") == 0) { e->fused_proj = value != 0; return LG_OK; }
     if (std::strcmp(key, "fused_next") == 0) { e->fused_next = value != 0; return LG_OK; }
+    if (std::strcmp(key, "profile_only") == 0) { e->prof_only = value; return LG_OK; }   // kernel class index, -1 = all classes
     if (std::strcmp(key, "tail_timing") == 0) { e->tail_timing = value; return LG_OK; }   // 1: tail kernel, 2: self projection, 3: self attention (LG_ATTN_TIMING builds)
     return fail(LG_ERR_INVALID, std::string("unknown option '") + key + "'");
 }

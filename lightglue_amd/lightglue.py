@@ -230,12 +230,13 @@ class LightGlue(nn.Module):
         return handle
 
     def _drop_engine(self):
-        if getattr(self, "_engine", None) is not None:
+        eng = self.__dict__.get("_engine")
+        if eng is not None:
+            self.__dict__["_engine"] = None   # not via nn.Module.__setattr__: this also runs at interpreter shutdown
             try:
-                _cabi.load().lg_engine_destroy(self._engine[0])
+                _cabi.load().lg_engine_destroy(eng[0])
             except Exception:  # pragma: no cover
                 pass
-            self._engine = None
 
     def __del__(self):  # pragma: no cover
         self._drop_engine()
@@ -418,9 +419,17 @@ class LightGlue(nn.Module):
         _cabi.check(_cabi.load().lg_engine_set_option(h, key.encode(), int(value)))
 
     # ------------------------------------------------------------------ per-kernel timing (HIP events)
-    def profile(self, enable: bool, device="cuda"):
+    def profile(self, enable: bool, device="cuda", only: str = None):
+        """HIP-event timing per kernel class on the launch stream; `only` = one class name (see profile_read) to
+        bracket just that class and leave every other launch untouched."""
+        lib = _cabi.load()
         h = self._get_engine(torch.device(device))
-        _cabi.check(_cabi.load().lg_engine_profile_enable(h, int(bool(enable))))
+        cls = -1
+        if only is not None:
+            names = [lib.lg_profile_class_name(i).decode() for i in range(lib.lg_profile_num_classes())]
+            cls = names.index(only)
+        _cabi.check(lib.lg_engine_set_option(h, b"profile_only", cls))
+        _cabi.check(lib.lg_engine_profile_enable(h, int(bool(enable))))
 
     def profile_read(self, device="cuda") -> dict:
         """{kernel class: (total ms, launch sites)} accumulated since the last read."""

@@ -169,11 +169,13 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
         float m_new[2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            float mx = fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3]));
-#pragma unroll
-            for (int kt = 1; kt < 4; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(s[kt][qt][0], s[kt][qt][1]), fmaxf(s[kt][qt][2], s[kt][qt][3])));
+            // 16 scores per lane and query tile: a depth-3 tree of v_max3
+            const float t0 = vmax3(s[0][qt][0], s[0][qt][1], s[0][qt][2]), t1 = vmax3(s[0][qt][3], s[1][qt][0], s[1][qt][1]);
+            const float t2 = vmax3(s[1][qt][2], s[1][qt][3], s[2][qt][0]), t3 = vmax3(s[2][qt][1], s[2][qt][2], s[2][qt][3]);
+            const float t4 = vmax3(s[3][qt][0], s[3][qt][1], s[3][qt][2]);
+            float mx = vmax2(vmax3(t0, t1, t2), vmax3(t3, t4, s[3][qt][3]));
             mx = xor32_max(xor16_max(mx));   // the 4 lane groups of a query column, no LDS round trip
-            m_new[qt] = fmaxf(m_run[qt], mx * a.scale_log2e);   // finite: every tile holds >= 1 live key (scale > 0)
+            m_new[qt] = vmax2(m_run[qt], mx * a.scale_log2e);   // finite: every tile holds >= 1 live key (scale > 0)
         }
         ATT_TICK(3);
         // Deferred rescale (guide T13): keep the stale running maximum while no row's maximum grew by more than
@@ -194,16 +196,20 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
         }
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            float rs = 0.f;
+            // exp2(s*c - m): packed fma (two scores per v_pk_fma_f32) + the bare v_exp_f32 (arguments <= 8, flush-to-zero tail
+            // is fine); row sums as packed adds
+            const f32x2 sc = {a.scale_log2e, a.scale_log2e}, nm = {-m_run[qt], -m_run[qt]};
+            f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    // exp2(s*c - m): one fma + the bare v_exp_f32 (arguments <= 0, flush-to-zero tail is fine)
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], a.scale_log2e, -m_run[qt]));
-                    s[kt][qt][r] = p;
-                    rs += p;
+                for (int h = 0; h < 4; h += 2) {
+                    const f32x2 e = f32x2{s[kt][qt][h], s[kt][qt][h + 1]} * sc + nm;
+                    const f32x2 p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+                    s[kt][qt][h] = p[0]; s[kt][qt][h + 1] = p[1];
+                    rs2 += p;
                 }
+            const float rs = rs2[0] + rs2[1];
             l_run[qt] += rs;
         }
         ATT_TICK(4);

@@ -135,6 +135,12 @@ template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
 // Cross-row exchanges without LDS (gfx950 v_permlane16_swap / v_permlane32_swap; __shfl_xor = ds_bpermute is an
 // LDS round trip).  With both operands = x: swap16 leaves {x.row0, x.row0, x.row2, x.row2} / {x.row1, x.row1, x.row3,
 // x.row3}, swap32 leaves {x.lo, x.lo} / {x.hi, x.hi} — combining the two halves IS the xor-16 / xor-32 reduction step.
+// Bare v_max_f32 / v_max3_f32: fmaxf() makes hipcc canonicalise each operand first (v_max x, x, x: one extra VALU op per
+// value in IEEE mode, see the guide's T17 / "canonicalising v_max" note); the operands here come straight out of MFMAs
+// or other arithmetic and are never signalling NaNs.
+__device__ __forceinline__ float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 // (elements are copied to scalars before the bit_cast: __builtin_bit_cast on `r[1]` directly reads element 0 with this clang)
 struct SwapPair { float a, b; };
 __device__ __forceinline__ SwapPair swap16(float x) {
@@ -147,8 +153,8 @@ __device__ __forceinline__ SwapPair swap32(float x) {
     const unsigned lo = r[0], hi = r[1];
     return {__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi)};
 }
-__device__ __forceinline__ float xor16_max(float x) { const SwapPair p = swap16(x); return fmaxf(p.a, p.b); }
-__device__ __forceinline__ float xor32_max(float x) { const SwapPair p = swap32(x); return fmaxf(p.a, p.b); }
+__device__ __forceinline__ float xor16_max(float x) { const SwapPair p = swap16(x); return vmax2(p.a, p.b); }
+__device__ __forceinline__ float xor32_max(float x) { const SwapPair p = swap32(x); return vmax2(p.a, p.b); }
 __device__ __forceinline__ float xor16_sum(float x) { const SwapPair p = swap16(x); return p.a + p.b; }
 __device__ __forceinline__ float xor32_sum(float x) { const SwapPair p = swap32(x); return p.a + p.b; }
 __device__ __forceinline__ float dpp_xor1(float v) { return dpp_mov<0xB1>(v); }   // quad_perm [1,0,3,2]

@@ -10,11 +10,12 @@
 // query row lives in ONE lane column (lane & 15): the online-softmax max/sum run over a lane's own
 // registers plus two cross-lane steps (lane groups g = 0..3), the rescale factor is a per-lane
 // scalar, and P^T leaves the S^T accumulators already in B-operand order for the PV MFMA:
-//   S^T acc[kt][qt][r] <-> key = 16*kt + 4*g + r, query = 16*qt + (lane & 15)
-//   16-bit PV chunk tp: B element j of lane group g <-> key 32*tp + 16*(j>>2) + 4*g + (j&3)
-//   f32    PV chunk kt: B element i                <-> key 16*kt + 4*g + i
-// V is produced TRANSPOSED by the projection GEMM ([head][d][row]) so the matching A operand is a
-// pair of 8-byte (16-bit) or one 16-byte (f32) contiguous LDS reads.
+//   f32:    S^T acc[kt][qt][r] <-> key 16*kt + 4*g + r;  PV chunk kt: B element i <-> key 16*kt + 4*g + i
+//   16-bit: the K rows feeding S^T tile kt are PERMUTED (a free choice: which K row a lane reads) so that the 8
+//           probabilities a lane group packs for PV chunk tp are 8 CONSECUTIVE keys:
+//           S^T acc[kt][qt][r] <-> key 32*(kt>>1) + 8*g + 4*(kt&1) + r,   PV chunk tp: B element j <-> key 32*tp + 8*g + j
+// V is produced TRANSPOSED by the projection ([head][d][row]) so the matching A operand is ONE contiguous 16-byte
+// LDS read per fragment in both cases (the natural order needed two 8-byte reads + register shuffles).
 // The S matrix never touches HBM.  Softmax runs in fp32 with exp2 and a folded log2(e)/sqrt(64).
 #include "lg_kernels.h"
 
@@ -38,6 +39,13 @@ __device__ __forceinline__ u32x4 mask_tail(u32x4 v, int nvalid) {  // keep the f
         }
     }
     return v;
+}
+
+// K tile swizzle.  16-bit: a 16-lane ds_read_b128 group reads rows {8j + 4h + i : j, i = 0..3} (permuted key order), so
+// the slot XOR is built from row bits 1, 3, 4 (8 values x 2 row parities = all 64 banks); f32 keeps lds_off<256>.
+template <int ROWB> __device__ __forceinline__ int k_off(int row, int slot16) {
+    if constexpr (ROWB == 128) return row * 128 + ((slot16 ^ (((row >> 1) & 1) | (((row >> 3) & 3) << 1))) << 4);
+    else return lds_off<ROWB>(row, slot16);
 }
 
 template <class Tag>
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
 #pragma unroll
             for (int i = 0; i < NCT; ++i) {
                 const int c = tid + ATHREADS * i, row = c / SLOTS, slot = c % SLOTS;
-                *reinterpret_cast<u32x4*>(smK + lds_off<ROWB>(row, slot)) = rk[i];
+                *reinterpret_cast<u32x4*>(smK + k_off<ROWB>(row, slot)) = rk[i];
                 *reinterpret_cast<u32x4*>(smV + lds_off<ROWB>(row, slot)) = rv[i];
             }
         } else {
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
                 // rows/keys past the live length may hold anything (uninitialised workspace): zero them so
                 // that 0-probabilities never multiply a NaN
                 const u32x4 kz = (kv0 + row < kvlen) ? rk[i] : u32x4{0u, 0u, 0u, 0u};
-                *reinterpret_cast<u32x4*>(smK + lds_off<ROWB>(row, slot)) = kz;
+                *reinterpret_cast<u32x4*>(smK + k_off<ROWB>(row, slot)) = kz;
                 *reinterpret_cast<u32x4*>(smV + lds_off<ROWB>(row, slot)) = mask_tail<Tag>(rv[i], kvlen - (kv0 + slot * EPC));
             }
         }
@@ -150,7 +158,8 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
         for (int c = 0; c < NC; ++c) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const u32x4 kf = *reinterpret_cast<const u32x4*>(smK + lds_off<ROWB>(kt * 16 + lr, c * 4 + g));
+                const int krow = EPC == 8 ? 32 * (kt >> 1) + 8 * (lr >> 2) + 4 * (kt & 1) + (lr & 3) : kt * 16 + lr;
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(smK + k_off<ROWB>(krow, c * 4 + g));
                 mma_chunk<Tag>(s[kt][0], kf, qf[0][c]);
                 mma_chunk<Tag>(s[kt][1], kf, qf[1][c]);
             }
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (kv0 + kt * 16 + g * 4 + r >= kvlen) s[kt][qt][r] = -INFINITY;
+                        if (kv0 + (EPC == 8 ? 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) : kt * 16 + g * 4) + r >= kvlen) s[kt][qt][r] = -INFINITY;
         }
         float m_new[2];
 #pragma unroll
@@ -221,10 +230,7 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
                 const u32x4 p1 = pack8<Tag>(s[2 * tp][1], s[2 * tp + 1][1]);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    const int drow = dt * 16 + lr;
-                    const u32x2 v0 = *reinterpret_cast<const u32x2*>(smV + lds_off<ROWB>(drow, 4 * tp + (g >> 1)) + (g & 1) * 8);
-                    const u32x2 v1 = *reinterpret_cast<const u32x2*>(smV + lds_off<ROWB>(drow, 4 * tp + 2 + (g >> 1)) + (g & 1) * 8);
-                    const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
+                    const u32x4 vf = *reinterpret_cast<const u32x4*>(smV + lds_off<ROWB>(dt * 16 + lr, 4 * tp + g));   // keys 32tp + 8g .. +7
                     mma_chunk<Tag>(o[dt][0], vf, p0);
                     mma_chunk<Tag>(o[dt][1], vf, p1);
                 }

@@ -146,6 +146,21 @@ int lg_sp_sample_descriptors(const float* desc_map, int32_t batch, int32_t chann
                              const float* keypoints, const int32_t* num, int32_t n, int32_t cell,
                              int32_t normalize_dense, float* workspace, float* out, void* hip_stream);
 
+/* Keypoint extraction from SuperPoint's dense score map: replaces simple_nms (lightglue/superpoint.py:52-70), the
+ * border removal, thresholding, per-image split (:186-204), top_k_keypoints (:73-77, :207-215) and the (y, x) -> (x, y)
+ * float conversion (:218).  Bit-identical to the reference (all comparisons are exact; ties inside top-k, which
+ * torch.topk leaves unspecified, go to the lower row-major index).
+ *   scores [B][H][W] fp32 (H, W < 32768); nms_radius <= 4; max_keypoints <= 0 keeps every detection in row-major
+ *   order, otherwise (<= 4096) the max_keypoints best sorted by score when more were found (the reference's rule).
+ *   keypoints [B][capacity][2] (x, y), kp_scores [B][capacity], counts [B] rows written per image;
+ *   totals [B] or NULL: detections above the threshold before top-k / clipping (> max_candidates = overflow).
+ *   workspace: lg_sp_detect_workspace_bytes(...) bytes of device scratch. */
+int64_t lg_sp_detect_workspace_bytes(int32_t batch, int32_t h, int32_t w, int32_t max_candidates);
+int lg_sp_detect(const float* scores, int32_t batch, int32_t h, int32_t w, int32_t nms_radius, int32_t remove_borders,
+                 float detection_threshold, int32_t max_keypoints, int32_t capacity, int32_t max_candidates,
+                 void* workspace, int64_t workspace_bytes, float* keypoints, float* kp_scores, int32_t* counts,
+                 int32_t* totals, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

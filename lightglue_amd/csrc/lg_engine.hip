@@ -521,6 +521,45 @@ int lg_sp_sample_descriptors(const float* desc_map, int32_t batch, int32_t chann
     return LG_OK;
 }
 
+namespace {
+struct SpLayout { size_t mask_a, mask_b, nms, rows, cxy, csc, ctot, total; };
+SpLayout sp_layout(int B, int h, int w, int maxc) {
+    SpLayout l{}; size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~size_t(255); return o; };
+    const size_t px = (size_t)B * h * w;
+    l.mask_a = take(px); l.mask_b = take(px); l.nms = take(px * 4); l.rows = take((size_t)B * h * 4);
+    l.cxy = take((size_t)B * maxc * 4); l.csc = take((size_t)B * maxc * 4); l.ctot = take((size_t)B * 4); l.total = off;
+    return l;
+}
+}  // namespace
+
+int64_t lg_sp_detect_workspace_bytes(int32_t batch, int32_t h, int32_t w, int32_t max_candidates) {
+    if (batch < 1 || h < 1 || w < 1 || max_candidates < 1) return 0;
+    return (int64_t)sp_layout(batch, h, w, max_candidates).total;
+}
+
+int lg_sp_detect(const float* scores, int32_t batch, int32_t h, int32_t w, int32_t nms_radius, int32_t remove_borders,
+                 float detection_threshold, int32_t max_keypoints, int32_t capacity, int32_t max_candidates, void* workspace,
+                 int64_t workspace_bytes, float* keypoints, float* kp_scores, int32_t* counts, int32_t* totals, void* hip_stream) {
+    if (batch < 1 || h < 1 || w < 1 || h >= 32768 || w >= 32768) return fail(LG_ERR_INVALID, "bad score map size");
+    if (nms_radius < 0 || nms_radius > 4) return fail(LG_ERR_INVALID, "nms_radius must be in [0, 4]");
+    if (max_keypoints > SP_TOPK_MAX) return fail(LG_ERR_INVALID, "max_keypoints above 4096");
+    if (capacity < 1 || max_candidates < 1 || (max_keypoints > 0 && capacity < max_keypoints)) return fail(LG_ERR_INVALID, "bad capacity / max_candidates");
+    if (!scores || !workspace || !keypoints || !kp_scores || !counts) return fail(LG_ERR_INVALID, "null pointer");
+    const SpLayout l = sp_layout(batch, h, w, max_candidates);
+    if (workspace_bytes < (int64_t)l.total) return fail(LG_ERR_INVALID, "workspace too small (lg_sp_detect_workspace_bytes)");
+    char* ws = static_cast<char*>(workspace);
+    SpDetectArgs a{};
+    a.scores = scores; a.B = batch; a.H = h; a.W = w; a.radius = nms_radius; a.border = remove_borders; a.threshold = detection_threshold;
+    a.max_keypoints = max_keypoints; a.capacity = capacity; a.max_candidates = max_candidates;
+    a.mask_a = reinterpret_cast<unsigned char*>(ws + l.mask_a); a.mask_b = reinterpret_cast<unsigned char*>(ws + l.mask_b);
+    a.nms = reinterpret_cast<float*>(ws + l.nms); a.row_counts = reinterpret_cast<int*>(ws + l.rows);
+    a.cand_xy = reinterpret_cast<int*>(ws + l.cxy); a.cand_score = reinterpret_cast<float*>(ws + l.csc); a.cand_total = reinterpret_cast<int*>(ws + l.ctot);
+    a.keypoints = keypoints; a.kp_scores = kp_scores; a.counts = counts; a.totals = totals;
+    HIPCHK(launch_sp_detect(a, static_cast<hipStream_t>(hip_stream)));
+    return LG_OK;
+}
+
 int lg_engine_debug_caps(lg_engine* e, int32_t* cap0, int32_t* cap1) {
     if (!e || !cap0 || !cap1) return fail(LG_ERR_INVALID, "null argument");
     *cap0 = e->cur_cap0; *cap1 = e->cur_cap1;

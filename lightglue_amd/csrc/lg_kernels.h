@@ -165,4 +165,23 @@ struct SpArgs {
 };
 hipError_t launch_sp_sample(const SpArgs& a, hipStream_t s);
 
+// keypoint extraction from the dense score map (ref superpoint.py:52-70 simple_nms, :186-214)
+struct SpDetectArgs {
+    const float* scores;       // [B][H][W]
+    int B, H, W, radius, border; float threshold;
+    int max_keypoints;         // top-k (<= 0: keep all, ref :200-208), at most SP_TOPK_MAX
+    int capacity;              // rows of the outputs per image
+    int max_candidates;        // rows of the candidate buffers per image
+    // workspace pieces
+    unsigned char* mask_a; unsigned char* mask_b;   // [B][H][W]
+    float* nms;                // [B][H][W] scores after non-maximum suppression (0 elsewhere)
+    int* row_counts;           // [B][H]
+    int* cand_xy; float* cand_score; int* cand_total;   // [B][max_candidates] packed (y << 16 | x), [B][max_candidates], [B]
+    // outputs
+    float* keypoints; float* kp_scores; int* counts;    // [B][capacity][2] (x, y), [B][capacity], [B]
+    int* totals;               // optional [B]: pixels above the threshold before top-k / capacity clipping
+};
+constexpr int SP_TOPK_MAX = 4096;
+hipError_t launch_sp_detect(const SpDetectArgs& a, hipStream_t s);
+
 }  // namespace lg

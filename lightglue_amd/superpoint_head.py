@@ -52,3 +52,42 @@ def descriptor_head(keypoints: torch.Tensor, dense_descriptors: torch.Tensor, s:
     normalisation over channels, sampling at the keypoints, final normalisation, `[B, N, 256]` layout.
     `dense_descriptors` is the raw `convDb` output `[B, 256, H/8, W/8]`; rows >= num_keypoints[b] come back zero."""
     return _run(keypoints, dense_descriptors, s, True, num_keypoints)
+
+
+def detect_keypoints(scores: torch.Tensor, nms_radius: int = 4, remove_borders: int = 4, detection_threshold: float = 0.0005,
+                     max_num_keypoints: Optional[int] = None, capacity: Optional[int] = None):
+    """Keypoint extraction of SuperPoint.forward (superpoint.py:186-218) on the dense score map `scores [B, H, W]`
+    (after softmax / depth-to-space, :176-184): simple_nms, border removal, threshold, optional top-k.
+
+    Returns `(keypoints [B, C, 2] float (x, y), keypoint_scores [B, C], num_keypoints [B] int32)` — a ragged batch in
+    the form `LightGlue.forward` / `descriptor_head` take (`num_keypoints`); rows >= num_keypoints[b] are undefined.
+    C = `capacity` (default: max_num_keypoints, or 1/8 of the pixels when it is None).  Without top-k, raises if an
+    image has more detections than `capacity` rows (the internal candidate buffer always holds every pixel)."""
+    if scores.device.type != "cuda":
+        raise RuntimeError("lightglue_amd.superpoint_head runs on MI355X (ROCm device type 'cuda') only; there is no "
+                           f"CPU fallback. Got scores on {scores.device}.")
+    if max_num_keypoints is not None and max_num_keypoints <= 0:
+        raise ValueError("max_num_keypoints must be positive or None")   # ref superpoint.py:143-144
+    b, h, w = scores.shape
+    device = scores.device
+    scores = scores.detach().to(dtype=torch.float32).contiguous()
+    k = int(max_num_keypoints) if max_num_keypoints is not None else 0
+    cap = int(capacity) if capacity is not None else (k if k > 0 else max(1, h * w // 8))
+    maxc = h * w   # candidates before top-k: worst case every pixel (8 bytes each, twice the score map)
+    lib = _cabi.load()
+    nbytes = lib.lg_sp_detect_workspace_bytes(b, h, w, maxc)
+    work = torch.empty((nbytes,), device=device, dtype=torch.uint8)
+    kpts = torch.empty((b, cap, 2), device=device, dtype=torch.float32)
+    kscores = torch.empty((b, cap), device=device, dtype=torch.float32)
+    counts = torch.empty((b,), device=device, dtype=torch.int32)
+    totals = torch.empty((b,), device=device, dtype=torch.int32)
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        _cabi.check(lib.lg_sp_detect(scores.data_ptr(), b, h, w, int(nms_radius), int(remove_borders), float(detection_threshold), k, cap,
+                                     maxc, work.data_ptr(), nbytes, kpts.data_ptr(), kscores.data_ptr(), counts.data_ptr(),
+                                     totals.data_ptr(), C.c_void_p(stream)))
+    if k == 0:
+        worst = int(totals.max().item())
+        if worst > cap:
+            raise RuntimeError(f"{worst} detections in one image exceed `capacity` = {cap} output rows; pass a larger one")
+    return kpts, kscores, counts

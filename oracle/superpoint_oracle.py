@@ -46,3 +46,43 @@ def sample_descriptors(keypoints: np.ndarray, descriptors: np.ndarray, s: int = 
 def descriptor_head(keypoints: np.ndarray, dense: np.ndarray, s: int = 8) -> np.ndarray:
     """ref superpoint.py:216-228: normalise the dense map over channels, sample, -> [b, N, c]."""
     return sample_descriptors(keypoints, l2_normalize(dense, 1), s).transpose(0, 2, 1).copy()
+
+
+# --------------------------------------------------------------------------- keypoint extraction
+def max_pool(x: np.ndarray, r: int) -> np.ndarray:
+    """F.max_pool2d(kernel 2r+1, stride 1, padding r) on [H, W] (padding value -inf)."""
+    h, w = x.shape
+    p = np.full((h + 2 * r, w + 2 * r), -np.inf, dtype=x.dtype)
+    p[r:r + h, r:r + w] = x
+    out = np.full_like(x, -np.inf)
+    for dy in range(2 * r + 1):
+        for dx in range(2 * r + 1):
+            out = np.maximum(out, p[dy:dy + h, dx:dx + w])
+    return out
+
+
+def simple_nms(scores: np.ndarray, nms_radius: int) -> np.ndarray:
+    """ref superpoint.py:52-70 for one [H, W] map."""
+    zeros = np.zeros_like(scores)
+    max_mask = scores == max_pool(scores, nms_radius)                                   # ref :62
+    for _ in range(2):                                                                  # ref :63
+        supp_mask = max_pool(max_mask.astype(np.float32), nms_radius) > 0               # ref :64
+        supp_scores = np.where(supp_mask, zeros, scores)                                # ref :65
+        new_max_mask = supp_scores == max_pool(supp_scores, nms_radius)                 # ref :66
+        max_mask = max_mask | (new_max_mask & (~supp_mask))                             # ref :67
+    return np.where(max_mask, scores, zeros)                                            # ref :68
+
+
+def detect_keypoints(scores: np.ndarray, nms_radius=4, remove_borders=4, detection_threshold=0.0005, max_num_keypoints=None):
+    """ref superpoint.py:186-218 for one image: returns (keypoints [K, 2] float (x, y), scores [K])."""
+    s = simple_nms(scores.astype(np.float32), nms_radius)
+    if remove_borders:                                                                  # ref :189-194
+        pad = remove_borders
+        s = s.copy()
+        s[:pad] = -1; s[:, :pad] = -1; s[-pad:] = -1; s[:, -pad:] = -1
+    ys, xs = np.where(s > np.float32(detection_threshold))                              # ref :197 (row-major)
+    sc = s[ys, xs]
+    if max_num_keypoints is not None and max_num_keypoints < len(sc):                   # ref :73-77
+        order = np.lexsort((np.arange(len(sc)), -sc.astype(np.float64)))[:max_num_keypoints]   # score desc, index asc on ties
+        ys, xs, sc = ys[order], xs[order], sc[order]
+    return np.stack([xs, ys], -1).astype(np.float32), sc                                # ref :218

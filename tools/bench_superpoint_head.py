@@ -29,3 +29,17 @@ ms = e0.elapsed_time(e1) / reps
 bytes_alg = B * (2 * 4 * 256 * h * w + N * 5 * 1024)
 print(json.dumps({"workload": f"B={B} map={h}x{w}x256 N={N}", "ms": ms, "images_per_s": B / ms * 1e3,
                   "algorithmic_GB": bytes_alg / 1e9, "achieved_GBps": bytes_alg / ms / 1e6, "frac_of_8TBps": bytes_alg / ms / 1e6 / 8000}))
+
+# keypoint extraction on the matching score maps (8 x 768 x 1024), top-2048
+smap = torch.rand(B, h * 8, w * 8, device="cuda", generator=g) ** 6
+for _ in range(3):
+    H.detect_keypoints(smap, max_num_keypoints=2048)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(20):
+    H.detect_keypoints(smap, max_num_keypoints=2048)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 20
+print(json.dumps({"workload": f"detect_keypoints B={B} map={h * 8}x{w * 8} top-2048", "ms": ms, "images_per_s": B / ms * 1e3,
+                  "score_map_GB": B * h * w * 64 * 4 / 1e9}))

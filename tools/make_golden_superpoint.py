@@ -59,9 +59,61 @@ def load_reference_functions():
     return mod
 
 
+# keypoint extraction: name -> (seed, B, H, W, max_num_keypoints)
+DETECT_CASES = {
+    "superpoint_detect_b2_120x160": (0, 2, 120, 160, None),
+    "superpoint_detect_b1_240x320_top300": (1, 1, 240, 320, 300),
+    "superpoint_detect_b2_67x91_top50": (2, 2, 67, 91, 50),
+}
+
+
+def score_map(seed: int, b: int, h: int, w: int):
+    """A keypoint score map shaped like SuperPoint's (softmax probabilities, mostly tiny, smooth blobs + isolated peaks
+    + exact ties on plateaus, which are what simple_nms's equality tests are sensitive to)."""
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    s = rng.random((b, h, w), dtype=np.float32) ** 8 * 0.3
+    yy, xx = np.mgrid[0:h, 0:w]
+    for i in range(b):
+        for _ in range(40):
+            cy, cx, a = rng.integers(0, h), rng.integers(0, w), rng.uniform(0.05, 0.9)
+            s[i] += (a * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / rng.uniform(2.0, 30.0))).astype(np.float32)
+        for _ in range(12):   # plateaus: equal neighbouring values
+            cy, cx = rng.integers(0, h - 3), rng.integers(0, w - 3)
+            s[i, cy:cy + rng.integers(1, 4), cx:cx + rng.integers(1, 4)] = np.float32(rng.uniform(0.3, 0.8))
+    return np.clip(s, 0, 1).astype(np.float32)
+
+
+def reference_detect(ref, scores: torch.Tensor, nms_radius=4, remove_borders=4, detection_threshold=0.0005, max_num_keypoints=None):
+    """The reference's own simple_nms / top_k_keypoints around a restatement of the few tensor statements of
+    SuperPoint.forward in between (superpoint.py:186-218), which cannot be called without the conv stack."""
+    b = scores.shape[0]
+    scores = ref.simple_nms(scores, nms_radius)                                       # ref :186
+    if remove_borders:                                                                # ref :189-194
+        pad = remove_borders
+        scores[:, :pad] = -1; scores[:, :, :pad] = -1; scores[:, -pad:] = -1; scores[:, :, -pad:] = -1
+    best_kp = torch.where(scores > detection_threshold)                               # ref :197
+    sc = scores[best_kp]
+    keypoints = [torch.stack(best_kp[1:3], dim=-1)[best_kp[0] == i] for i in range(b)]
+    sc = [sc[best_kp[0] == i] for i in range(b)]
+    if max_num_keypoints is not None:                                                 # ref :207-215
+        keypoints, sc = list(zip(*[ref.top_k_keypoints(k, s, max_num_keypoints) for k, s in zip(keypoints, sc)]))
+    keypoints = [torch.flip(k, [1]).float() for k in keypoints]                       # ref :218
+    return keypoints, list(sc)
+
+
 def main():
     ref = load_reference_functions()
     out_dir = ROOT / "tests" / "golden"
+    for name, (seed, b, h, w, topk) in DETECT_CASES.items():
+        smap = score_map(seed, b, h, w)
+        with torch.no_grad():
+            nms = ref.simple_nms(torch.from_numpy(smap.copy()), 4).numpy()
+            kps, scs = reference_detect(ref, torch.from_numpy(smap.copy()), max_num_keypoints=topk)
+        arrays = {"case": np.array([seed, b, h, w, -1 if topk is None else topk]), "nms_nonzero": np.packbits(nms != 0)}
+        for i in range(b):
+            arrays[f"kp{i}"] = kps[i].numpy(); arrays[f"sc{i}"] = scs[i].numpy()
+        np.savez_compressed(out_dir / f"{name}.npz", **arrays)
+        print(name, [len(k) for k in kps])
     for name, (seed, b, h, w, n) in CASES.items():
         dense, kp = head_inputs(seed, b, h, w, n)
         with torch.no_grad():

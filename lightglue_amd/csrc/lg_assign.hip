@@ -24,11 +24,23 @@ __device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2
     m = mn;
 }
 
-// Both sweeps use the same decomposition: workgroup = ART rows x all columns; thread = 4 consecutive
-// columns (one float4 per row, a wave reads 1 KB contiguous), looping over the tile's rows and, for
-// n > 1024, over column passes.  Row statistics are per-thread partials reduced across the workgroup at
-// the end; column statistics are per-row-tile partials [tile][column] merged by the next kernel.
+// Both sweeps use the same decomposition: workgroup = ART rows x all columns; thread = 4 consecutive columns (one float4
+// per row, a wave reads 1 KB contiguous), looping over the tile's rows and, for n > 1024, over column passes.
+// The row loop is a REAL loop with a ~200-instruction body: each row's statistic is reduced across the wave right away
+// (DPP + permlane, no LDS) and lane 0 folds it into an LDS slot.  The first version kept 32 per-row partials in
+// registers and fully unrolled both the row loop and the 32 x 6-step reduction: 58 KB of straight-line code executed
+// exactly once per wave, i.e. instruction-fetch-bound (the reduction alone was 54 of the kernel's 114 us).
+// Column statistics are per-thread registers across the rows, written as per-row-tile partials [tile][column] and
+// merged by the next kernel.
 constexpr int ART = 32;
+
+// (m, s) <- log-sum-exp merge with (m2, s2), ONE exponential: e = exp(-|m - m2|) scales the smaller side
+__device__ __forceinline__ void lse_merge1(float& m, float& s, float m2, float s2) {
+    const float e = (m == m2) ? 1.f : fexp(-fabsf(m - m2));   // m == m2 also covers (-inf, -inf), whose difference is NaN
+    const bool keep = m >= m2;
+    s = keep ? __builtin_fmaf(s2, e, s) : __builtin_fmaf(s, e, s2);
+    m = keep ? m : m2;
+}
 
 // ---- sweep 1: row log-sum-exp + column (max, sum-exp) partials.  grid (cap0/ART, B)
 __global__ __launch_bounds__(256) void lse_sweep_kernel(AssignArgs a) {
@@ -36,51 +48,45 @@ __global__ __launch_bounds__(256) void lse_sweep_kernel(AssignArgs a) {
     const int len0 = a.rs.len[2 * pair], len1 = a.rs.len[2 * pair + 1];
     const int r0 = tile * ART;
     if (r0 >= len0) return;
+    const int rows = min(ART, len0 - r0);
     const int ntiles = a.rs.cap0 / ART;
     const float* simp = a.sim + ((long long)pair * a.rs.cap0 + r0) * a.rs.cap1;
     float* pm = a.cpm + ((long long)pair * ntiles + tile) * a.rs.cap1;
     float* ps = a.cps + ((long long)pair * ntiles + tile) * a.rs.cap1;
-    float rm[ART], rsum[ART];
-#pragma unroll
-    for (int r = 0; r < ART; ++r) { rm[r] = -INFINITY; rsum[r] = 0.f; }
-    for (int c = tid * 4; c < len1; c += 1024) {
+    __shared__ float shm[4][ART], shs[4][ART];
+    for (int c0 = 0; c0 < len1; c0 += 1024) {             // workgroup-uniform trip count
+        const int c = c0 + tid * 4;
+        const bool act = c < len1;                         // this thread's 4 columns hold at least one live column
+        const float* col = simp + (act ? c : 0);
         float cm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, cs[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x4 nxt = *reinterpret_cast<const f32x4*>(col);
+#pragma unroll 1
+        for (int r = 0; r < rows; ++r) {
+            f32x4 v = nxt;
+            nxt = *reinterpret_cast<const f32x4*>(col + (long long)min(r + 1, rows - 1) * a.rs.cap1);   // next row in flight
 #pragma unroll
-        for (int r = 0; r < ART; ++r) {
-            if (r0 + r < len0) {   // workgroup-uniform
-                f32x4 v = *reinterpret_cast<const f32x4*>(simp + (long long)r * a.rs.cap1 + c);
+            for (int i = 0; i < 4; ++i) if (!act || c + i >= len1) v[i] = -INFINITY;
+            const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            float m = m4, sum = act ? (fexp(v[0] - m4) + fexp(v[1] - m4)) + (fexp(v[2] - m4) + fexp(v[3] - m4)) : 0.f;
+            if (act) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) if (c + i >= len1) v[i] = -INFINITY;
-                const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));   // finite: column c itself is live
-                const float mn = fmaxf(rm[r], m4);
-                rsum[r] = rsum[r] * fexp(rm[r] - mn) + (fexp(v[0] - mn) + fexp(v[1] - mn)) + (fexp(v[2] - mn) + fexp(v[3] - mn));
-                rm[r] = mn;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (v[i] > cm[i]) { cs[i] = cs[i] * fexp(cm[i] - v[i]) + 1.f; cm[i] = v[i]; }
-                    else cs[i] += fexp(v[i] - cm[i]);
-                }
+                for (int i = 0; i < 4; ++i) lse_merge1(cm[i], cs[i], v[i], v[i] == -INFINITY ? 0.f : 1.f);
+            }
+            wave_allreduce2(m, sum, [](float& m0, float& s0, float m2, float s2) { lse_merge1(m0, s0, m2, s2); });
+            if (lane == 0) {
+                if (c0 == 0) { shm[wave][r] = m; shs[wave][r] = sum; }
+                else { float mo = shm[wave][r], so = shs[wave][r]; lse_merge1(mo, so, m, sum); shm[wave][r] = mo; shs[wave][r] = so; }
             }
         }
-        *reinterpret_cast<f32x4*>(pm + c) = f32x4{cm[0], cm[1], cm[2], cm[3]};
-        *reinterpret_cast<f32x4*>(ps + c) = f32x4{cs[0], cs[1], cs[2], cs[3]};
-    }
-    // row reduction across the workgroup: wave-level first (DPP/permute), then 4 waves through LDS
-    __shared__ float shm[4][ART], shs[4][ART];
-#pragma unroll
-    for (int r = 0; r < ART; ++r) {
-        float m = rm[r], s = rsum[r];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
-            lse_merge(m, s, m2, s2);
+        if (act) {
+            *reinterpret_cast<f32x4*>(pm + c) = f32x4{cm[0], cm[1], cm[2], cm[3]};
+            *reinterpret_cast<f32x4*>(ps + c) = f32x4{cs[0], cs[1], cs[2], cs[3]};
         }
-        if (lane == 0) { shm[wave][r] = m; shs[wave][r] = s; }
     }
     __syncthreads();
-    if (tid < ART && r0 + tid < len0) {
+    if (tid < rows) {
         float m = shm[0][tid], s = shs[0][tid];
-        for (int w = 1; w < 4; ++w) lse_merge(m, s, shm[w][tid], shs[w][tid]);
+        for (int w = 1; w < 4; ++w) lse_merge1(m, s, shm[w][tid], shs[w][tid]);
         a.lse_r[(long long)pair * a.rs.cap0 + r0 + tid] = m + logf(s);
     }
 }
@@ -108,6 +114,7 @@ __global__ __launch_bounds__(256) void argmax_sweep_kernel(AssignArgs a) {
     const int len0 = a.rs.len[2 * pair], len1 = a.rs.len[2 * pair + 1];
     const int r0 = tile * ART;
     if (r0 >= len0) return;
+    const int rows = min(ART, len0 - r0);
     const int ntiles = a.rs.cap0 / ART;
     const float* simp = a.sim + ((long long)pair * a.rs.cap0 + r0) * a.rs.cap1;
     const float* lsec = a.lse_c + (long long)pair * a.rs.cap1;
@@ -116,44 +123,46 @@ __global__ __launch_bounds__(256) void argmax_sweep_kernel(AssignArgs a) {
     const float* ls0 = a.ls + seg_row_base(a.rs, 2 * pair) + r0;
     float* pv = a.cbv + ((long long)pair * ntiles + tile) * a.rs.cap1;
     int* pi = a.cbi + ((long long)pair * ntiles + tile) * a.rs.cap1;
-    float rb[ART]; int ri[ART];
-#pragma unroll
-    for (int r = 0; r < ART; ++r) { rb[r] = -INFINITY; ri[r] = 0x7fffffff; }
-    for (int c = tid * 4; c < len1; c += 1024) {
-        const f32x4 lc = *reinterpret_cast<const f32x4*>(lsec + c);
-        const f32x4 l1 = *reinterpret_cast<const f32x4*>(ls1 + c);
+    __shared__ float shb[4][ART]; __shared__ int shi[4][ART];
+    for (int c0 = 0; c0 < len1; c0 += 1024) {             // workgroup-uniform trip count
+        const int c = c0 + tid * 4;
+        const bool act = c < len1;
+        const int cc = act ? c : 0;
+        const float* col = simp + cc;
+        const f32x4 lc = *reinterpret_cast<const f32x4*>(lsec + cc);
+        const f32x4 l1 = *reinterpret_cast<const f32x4*>(ls1 + cc);
         float cb[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}; int ci[4] = {0, 0, 0, 0};
+        f32x4 nxt = *reinterpret_cast<const f32x4*>(col);
+#pragma unroll 1
+        for (int r = 0; r < rows; ++r) {
+            const f32x4 v = nxt;
+            nxt = *reinterpret_cast<const f32x4*>(col + (long long)min(r + 1, rows - 1) * a.rs.cap1);
+            const float lr = lser[r], l0 = ls0[r];
+            float best = -INFINITY; int bi = 0x7fffffff;
 #pragma unroll
-        for (int r = 0; r < ART; ++r) {
-            if (r0 + r < len0) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(simp + (long long)r * a.rs.cap1 + c);
-                const float lr = lser[r], l0 = ls0[r];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (c + i < len1) {
-                        const float sc = score_of(v[i], lr, lc[i], l0 + l1[i]);
-                        if (sc > rb[r]) { rb[r] = sc; ri[r] = c + i; }          // ascending columns per thread: first index wins
-                        if (sc > cb[i]) { cb[i] = sc; ci[i] = r0 + r; }          // ascending rows: first index wins
-                    }
+            for (int i = 0; i < 4; ++i) {
+                if (act && c + i < len1) {
+                    const float sc = score_of(v[i], lr, lc[i], l0 + l1[i]);
+                    if (sc > best) { best = sc; bi = c + i; }                 // ascending columns: first index wins
+                    if (sc > cb[i]) { cb[i] = sc; ci[i] = r0 + r; }           // ascending rows: first index wins
                 }
             }
+            float bif = __int_as_float(bi);   // the index travels as a bit pattern through the DPP moves
+            wave_allreduce2(best, bif, [](float& b0, float& i0, float b2, float i2) {
+                const int x = __float_as_int(i0), y = __float_as_int(i2);
+                if (b2 > b0 || (b2 == b0 && y < x)) { b0 = b2; i0 = i2; }
+            });
+            if (lane == 0) {
+                if (c0 == 0 || best > shb[wave][r]) { shb[wave][r] = best; shi[wave][r] = __float_as_int(bif); }   // later passes = higher columns: strict >
+            }
         }
-        *reinterpret_cast<f32x4*>(pv + c) = f32x4{cb[0], cb[1], cb[2], cb[3]};
-        *reinterpret_cast<int4*>(pi + c) = int4{ci[0], ci[1], ci[2], ci[3]};
-    }
-    __shared__ float shb[4][ART]; __shared__ int shi[4][ART];
-#pragma unroll
-    for (int r = 0; r < ART; ++r) {
-        float best = rb[r]; int bi = ri[r];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        if (act) {
+            *reinterpret_cast<f32x4*>(pv + c) = f32x4{cb[0], cb[1], cb[2], cb[3]};
+            *reinterpret_cast<int4*>(pi + c) = int4{ci[0], ci[1], ci[2], ci[3]};
         }
-        if (lane == 0) { shb[wave][r] = best; shi[wave][r] = bi; }
     }
     __syncthreads();
-    if (tid < ART && r0 + tid < len0) {
+    if (tid < rows) {
         float best = shb[0][tid]; int bi = shi[0][tid];
         for (int w = 1; w < 4; ++w) {
             const float ob = shb[w][tid]; const int oi = shi[w][tid];

@@ -168,6 +168,19 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// All-reduce of a commutative pair operation over the 64 lanes WITHOUT LDS: four DPP steps inside each row of 16 lanes
+// (xor 1, xor 2, half mirror, mirror), then the two permlane swaps across rows.  `__shfl_xor` would be six ds_bpermute
+// round trips per value; with 4 waves per SIMD reducing 32 rows each that was 46 % of the log-assignment LSE sweep.
+// merge(a0, a1, b0, b1) folds partner (b0, b1) into (a0, a1); both lanes of a pair must end with the same result.
+template <class F> __device__ __forceinline__ void wave_allreduce2(float& x0, float& x1, F merge) {
+    merge(x0, x1, dpp_xor1(x0), dpp_xor1(x1));
+    merge(x0, x1, dpp_xor2(x0), dpp_xor2(x1));
+    merge(x0, x1, dpp_mov<0x141>(x0), dpp_mov<0x141>(x1));
+    merge(x0, x1, dpp_mov<0x140>(x0), dpp_mov<0x140>(x1));
+    { const SwapPair p0 = swap16(x0), p1 = swap16(x1); x0 = p0.a; x1 = p1.a; merge(x0, x1, p0.b, p1.b); }
+    { const SwapPair p0 = swap32(x0), p1 = swap32(x1); x0 = p0.a; x1 = p1.a; merge(x0, x1, p0.b, p1.b); }
+}
+
 // ---- wave helpers (wave = 64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -797,6 +797,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
         as.m0 = io->matches0; as.m1 = io->matches1; as.s0 = io->scores0; as.s1 = io->scores1;
         as.matches = io->matches; as.mscores = io->match_scores; as.n_matches = io->n_matches; as.max_matches = max_matches;
         as.log_assignment = io->log_assignment; as.lsneg = e->MSCORE;
+        as.dbg = e->tail_timing == 4 ? e->TAILDBG : nullptr;
         TRY(prof_begin(e, PC_ASSIGN, s));
         HIPCHK(launch_assign(as, s));
         TRY(prof_end(e, s));

@@ -151,6 +151,7 @@ struct AssignArgs {
     int* matches; float* mscores; int* n_matches; int max_matches;
     // optional full log-assignment [B][n0+1][n1+1] (ref :265-277) + logsigmoid(-z) per row for its dustbins
     float* log_assignment; const float* lsneg;
+    long long* dbg;   // profiling tap (tail_timing == 4): per sweep workgroup [3] shader-clock stamps
 };
 hipError_t launch_assign(const AssignArgs& a, hipStream_t s);
 

@@ -1,7 +1,8 @@
-// standalone check of the permlane-swap reductions against __shfl_xor (run on the GPU box)
+// standalone check of the permlane-swap reductions against __shfl_xor (run on the GPU box):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/permlane_check tools/permlane_check.hip && /tmp/permlane_check
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../../lightglue_amd/csrc/lg_common.h"
+#include "../lightglue_amd/csrc/lg_common.h"
 __global__ void k(const float* in, float* out) {
     const float x = in[threadIdx.x];
     out[threadIdx.x] = lg::xor16_max(x);

@@ -21,7 +21,7 @@
 
 namespace lg {
 
-constexpr int ABM = 128, ABK = 64, ATHREADS = 256;
+constexpr int ABK = 64, ATHREADS = 256;   // query rows per workgroup = 64 * QT (QT 16-row query tiles per wave, 4 waves)
 
 template <class Tag>
 __device__ __forceinline__ u32x4 mask_tail(u32x4 v, int nvalid) {  // keep the first nvalid elements of the chunk
@@ -48,8 +48,9 @@ template <int ROWB> __device__ __forceinline__ int k_off(int row, int slot16) {
     else return lds_off<ROWB>(row, slot16);
 }
 
-template <class Tag>
+template <class Tag, int QT>
 __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
+    constexpr int ABM = 64 * QT;
     typedef typename Tag::elem T;
     constexpr int EPC = Tag::EPC;
     constexpr int ROWB = 64 * (int)sizeof(T);     // bytes per LDS tile row (128 or 256)
@@ -65,7 +66,18 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
     const int ntile = gridDim.x >> 2;
     const int v = xcd_remap(blockIdx.x, gridDim.x);
     const int head = v / ntile;
-    const TileLoc t = locate_tile(a.rs, v - head * ntile, ABM);
+    TileLoc t;
+    if constexpr (QT <= 2) {
+        t = locate_tile(a.rs, v - head * ntile, ABM);
+    } else {   // 256-row tiles are laid out per segment (capacities are multiples of 128, not of 256)
+        const int t0 = (a.rs.cap0 + ABM - 1) / ABM, t1 = (a.rs.cap1 + ABM - 1) / ABM, idx = v - head * ntile;
+        t.pair = idx / (t0 + t1);
+        const int rem = idx - t.pair * (t0 + t1);
+        t.image = rem >= t0 ? 1 : 0;
+        t.r0 = (rem - t.image * t0) * ABM;
+        t.seg = 2 * t.pair + t.image;
+        t.grow0 = seg_row_base(a.rs, t.seg) + t.r0;
+    }
     const int qlen = a.rs.len[t.seg];
     if (t.r0 >= qlen) return;
     if (a.rs.active && !a.rs.active[t.pair]) return;
@@ -88,19 +100,23 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
     }
 
     // Q fragments (B operand of S^T = K Q^T): lane supplies query column lr, k-slots of group g
-    u32x4 qf[2][NC];
+    u32x4 qf[QT][NC];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const long long grow = t.grow0 + wave * 32 + qt * 16 + lr;
+    for (int qt = 0; qt < QT; ++qt) {
+        const long long grow = min((long long)t.grow0 + wave * (16 * QT) + qt * 16 + lr, R - 1);   // a 256-row tile may overhang the last segment
 #pragma unroll
         for (int c = 0; c < NC; ++c)
             qf[qt][c] = *reinterpret_cast<const u32x4*>(Q + ((long long)head * R + grow) * 64 + c * 4 * EPC + g * EPC);
     }
 
-    f32x4 o[4][2];
+    f32x4 o[4][QT];
+    float m_run[QT], l_run[QT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { o[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    for (int qt = 0; qt < QT; ++qt) {
+        m_run[qt] = -INFINITY; l_run[qt] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     u32x4 rk[NCT], rv[NCT];
     auto load_tile = [&](int kv0) {
@@ -151,33 +167,36 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
         __builtin_amdgcn_sched_barrier(0);                // and pinned ahead of the MFMAs
 
         // ---- S^T = K Q^T  (4 key tiles x 2 query tiles)
-        f32x4 s[4][2];
+        f32x4 s[4][QT];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) { s[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 const int krow = EPC == 8 ? 32 * (kt >> 1) + 8 * (lr >> 2) + 4 * (kt & 1) + (lr & 3) : kt * 16 + lr;
                 const u32x4 kf = *reinterpret_cast<const u32x4*>(smK + k_off<ROWB>(krow, c * 4 + g));
-                mma_chunk<Tag>(s[kt][0], kf, qf[0][c]);
-                mma_chunk<Tag>(s[kt][1], kf, qf[1][c]);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(s[kt][qt], kf, qf[qt][c]);
             }
         }
         ATT_TICK(2);
         // ---- online softmax (fp32), per query column.  Only the last tile can hold dead keys.
         if (kv0 + ABK > kvlen) {   // wave-uniform
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
+            for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (kv0 + (EPC == 8 ? 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) : kt * 16 + g * 4) + r >= kvlen) s[kt][qt][r] = -INFINITY;
         }
-        float m_new[2];
+        float m_new[QT];
+        bool grew = false;
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             // 16 scores per lane and query tile: a depth-3 tree of v_max3
             const float t0 = vmax3(s[0][qt][0], s[0][qt][1], s[0][qt][2]), t1 = vmax3(s[0][qt][3], s[1][qt][0], s[1][qt][1]);
             const float t2 = vmax3(s[1][qt][2], s[1][qt][3], s[2][qt][0]), t3 = vmax3(s[2][qt][1], s[2][qt][2], s[2][qt][3]);
@@ -185,6 +204,7 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
             float mx = vmax2(vmax3(t0, t1, t2), vmax3(t3, t4, s[3][qt][3]));
             mx = xor32_max(xor16_max(mx));   // the 4 lane groups of a query column, no LDS round trip
             m_new[qt] = vmax2(m_run[qt], mx * a.scale_log2e);   // finite: every tile holds >= 1 live key (scale > 0)
+            grew = grew || (m_new[qt] > m_run[qt] + 8.f);
         }
         ATT_TICK(3);
         // Deferred rescale (guide T13): keep the stale running maximum while no row's maximum grew by more than
@@ -192,10 +212,9 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
         // l / O accumulators and nothing relative in the f16 / bf16 P operand.  Order is the textbook one: decide,
         // rescale o and l, THEN exponentiate this tile against the (possibly updated) maximum.  The first tile always
         // takes the branch (m_run = -inf); on most later tiles the O accumulators are not touched by the VALU at all.
-        constexpr float DEFER_LOG2 = 8.f;
-        if (__any((m_new[0] > m_run[0] + DEFER_LOG2) || (m_new[1] > m_run[1] + DEFER_LOG2))) {
+        if (__any(grew)) {   // threshold 2^8: see `grew` above
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
+            for (int qt = 0; qt < QT; ++qt) {
                 const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new[qt]);
                 l_run[qt] *= alpha;
 #pragma unroll
@@ -204,7 +223,7 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
             }
         }
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             // exp2(s*c - m): packed fma (two scores per v_pk_fma_f32) + the bare v_exp_f32 (arguments <= 8, flush-to-zero tail
             // is fine); row sums as packed adds
             const f32x2 sc = {a.scale_log2e, a.scale_log2e}, nm = {-m_run[qt], -m_run[qt]};
@@ -226,25 +245,24 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
         if constexpr (EPC == 8) {
 #pragma unroll
             for (int tp = 0; tp < 2; ++tp) {
-                const u32x4 p0 = pack8<Tag>(s[2 * tp][0], s[2 * tp + 1][0]);
-                const u32x4 p1 = pack8<Tag>(s[2 * tp][1], s[2 * tp + 1][1]);
+                u32x4 pp[QT];
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) pp[qt] = pack8<Tag>(s[2 * tp][qt], s[2 * tp + 1][qt]);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     const u32x4 vf = *reinterpret_cast<const u32x4*>(smV + lds_off<ROWB>(dt * 16 + lr, 4 * tp + g));   // keys 32tp + 8g .. +7
-                    mma_chunk<Tag>(o[dt][0], vf, p0);
-                    mma_chunk<Tag>(o[dt][1], vf, p1);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(o[dt][qt], vf, pp[qt]);
                 }
             }
         } else {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const u32x4 p0 = __builtin_bit_cast(u32x4, s[kt][0]);
-                const u32x4 p1 = __builtin_bit_cast(u32x4, s[kt][1]);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     const u32x4 vf = *reinterpret_cast<const u32x4*>(smV + lds_off<ROWB>(dt * 16 + lr, 4 * kt + g));
-                    mma_chunk<Tag>(o[dt][0], vf, p0);
-                    mma_chunk<Tag>(o[dt][1], vf, p1);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(o[dt][qt], vf, __builtin_bit_cast(u32x4, s[kt][qt]));
                 }
             }
         }
@@ -259,32 +277,36 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
 #endif
     // ---- normalise and store ctx[row][head*64 + d]
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         float l = l_run[qt];
         l = xor32_sum(xor16_sum(l));
         const float inv = 1.f / l;
-        const int qrow = t.r0 + wave * 32 + qt * 16 + lr;
+        const int qrow = t.r0 + wave * (16 * QT) + qt * 16 + lr;
         if (qrow < qlen) {
-            float* dst = a.ctx + (t.grow0 + wave * 32 + qt * 16 + lr) * 256LL + head * 64 + g * 4;
+            float* dst = a.ctx + (t.grow0 + wave * (16 * QT) + qt * 16 + lr) * 256LL + head * 64 + g * 4;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(dst + dt * 16) = o[dt][qt] * inv;
         }
     }
 }
 
-template <class Tag> static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t s) {
-    const int R = a.rs.B * (a.rs.cap0 + a.rs.cap1);
-    dim3 grid((R / ABM) * 4);
+template <class Tag, int QT> static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t s) {
+    constexpr int ABM = 64 * QT;
+    const int tiles = QT <= 2 ? a.rs.B * (a.rs.cap0 + a.rs.cap1) / ABM : a.rs.B * ((a.rs.cap0 + ABM - 1) / ABM + (a.rs.cap1 + ABM - 1) / ABM);
+    dim3 grid(tiles * 4);
     constexpr int smem = 2 * 64 * 64 * (int)sizeof(typename Tag::elem);
-    hipLaunchKernelGGL(attn_kernel<Tag>, grid, dim3(ATHREADS), smem, s, a);
+    hipLaunchKernelGGL((attn_kernel<Tag, QT>), grid, dim3(ATHREADS), smem, s, a);
     return hipGetLastError();
 }
 
+// a.rows_per_wave: 32 (two 16-row query tiles per wave, three waves per SIMD) or 64 (four tiles, two waves per SIMD, K/V
+// fragments reused twice as often; 16-bit operands only)
 hipError_t launch_attention(int attn_prec, const AttnArgs& a, hipStream_t s) {
+    const int rpw = a.rows_per_wave;
     switch (attn_prec) {
-        case PREC_F32: return launch_attn_t<TagF32>(a, s);
-        case PREC_BF16: return launch_attn_t<TagBF16>(a, s);
-        case PREC_F16: return launch_attn_t<TagF16>(a, s);
+        case PREC_F32: return launch_attn_t<TagF32, 2>(a, s);
+        case PREC_BF16: return rpw == 64 ? launch_attn_t<TagBF16, 4>(a, s) : rpw == 16 ? launch_attn_t<TagBF16, 1>(a, s) : launch_attn_t<TagBF16, 2>(a, s);
+        case PREC_F16: return rpw == 64 ? launch_attn_t<TagF16, 4>(a, s) : rpw == 16 ? launch_attn_t<TagF16, 1>(a, s) : launch_attn_t<TagF16, 2>(a, s);
     }
     return hipErrorInvalidValue;
 }

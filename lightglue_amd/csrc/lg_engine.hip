@@ -94,6 +94,7 @@ struct lg_engine {
     size_t tail_cat_layer_bytes = 0, tail_2_layer_bytes = 0;
     char *w_sqkv_p = nullptr, *w_cqkv_p = nullptr;   // fragment-packed projection weights (lg_proj.hip)
     size_t sqkv_layer_bytes = 0, cqkv_layer_bytes = 0;
+    int attn_rows = 32;   // query rows per attention wave (32 | 64), option "attn_rows" / env LG_ATTN_ROWS
     int fused_tail = 1, fused_proj = 1, fused_next = 1, tail_variant = 0;   // 0 = lg_tail.hip (64 rows, LDS-resident), 1 = 4 waves x 64 rows, 2 = 8 waves x 128 rows
     int tail_timing = 0; long long* TAILDBG = nullptr;
     // ---- workspace
@@ -318,7 +319,8 @@ int lg_engine_create(const lg_config* cfg, lg_engine** out) {
     if (ap < 0) ap = cfg->precision == LG_PREC_BF16X3 ? PREC_F16 : cfg->precision;
     if (ap != PREC_F32 && ap != PREC_BF16 && ap != PREC_F16) { delete e; return fail(LG_ERR_INVALID, "bad attn_precision"); }
     e->attn_prec = ap;
-    if (const char* tv = std::getenv("LG_TAIL_VARIANT")) e->tail_variant = std::atoi(tv);   // A/B switch for experiments
+    if (const char* tv = std::getenv("LG_TAIL_VARIANT")) e->tail_variant = std::atoi(tv);
+    if (const char* ar = std::getenv("LG_ATTN_ROWS")) { const int v = std::atoi(ar); e->attn_rows = (v == 64 || v == 16) ? v : 32; }   // A/B switch for experiments
     *out = e;
     return LG_OK;
 }
@@ -503,6 +505,7 @@ int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
     if (std::strcmp(key, "tail_variant") == 0) { e->tail_variant = value; return LG_OK; }
     if (std::strcmp(key, "fused_proj") == 0) { e->fused_proj = value != 0; return LG_OK; }
     if (std::strcmp(key, "fused_next") == 0) { e->fused_next = value != 0; return LG_OK; }
+    if (std::strcmp(key, "attn_rows") == 0) { if (value != 16 && value != 32 && value != 64) return fail(LG_ERR_INVALID, "attn_rows must be 16, 32 or 64"); e->attn_rows = value; return LG_OK; }
     if (std::strcmp(key, "profile_only") == 0) { e->prof_only = value; return LG_OK; }   // kernel class index, -1 = all classes
     if (std::strcmp(key, "tail_timing") == 0) { e->tail_timing = value; return LG_OK; }   // 1: tail kernel, 2: self projection, 3: self attention (LG_ATTN_TIMING builds)
     return fail(LG_ERR_INVALID, std::string("unknown option '") + key + "'");
@@ -686,6 +689,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 AttnArgs at{};
                 at.rs = rs_act; at.q = e->Q; at.k = e->K; at.vt = e->VT; at.ctx = e->CTX; at.R = R; at.cross = blk; at.scale_log2e = scale_log2e;
                 at.dbg = (e->tail_timing == 3 && blk == 0) ? e->TAILDBG : nullptr;
+                at.rows_per_wave = e->attn_rows;
                 TRY(prof_begin(e, blk == 0 ? PC_ATTN_SELF : PC_ATTN_CROSS, s));
                 HIPCHK(launch_attention(ap, at, s));
                 TRY(prof_end(e, s));

@@ -83,6 +83,7 @@ struct AttnArgs {
     int R; int cross; // cross: segment s attends to segment s^1 (q and k both read from `q`)
     float scale_log2e;
     long long* dbg;   // profiling builds (-DLG_ATTN_TIMING) only: [blocks][4 waves][8] phase clock sums
+    int rows_per_wave;   // 32 or 64 query rows per wave (see launch_attention)
 };
 hipError_t launch_attention(int attn_prec, const AttnArgs& a, hipStream_t s);
 

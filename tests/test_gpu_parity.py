@@ -283,6 +283,26 @@ def test_fused_next_projection_is_bit_identical(precision):
         assert torch.equal(torch.as_tensor(fused["stop"]), torch.as_tensor(plain["stop"]))
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_attention_rows_per_wave_variants_are_equivalent(precision):
+    """Engine option attn_rows = 64 / 16 (four / one 16-row query tiles per wave; 256-row workgroup tiles are laid out
+    per segment): same arithmetic per query row as the default 32-row kernel, so the outputs must be bit-identical — including
+    capacities that are not multiples of 256 (tiles overhang their segment and, for the last one, the row space)."""
+    require_gpu()
+    for (n0, n1, recipe, kw) in ((300, 333, "A", dict(depth_confidence=-1, width_confidence=-1)), (130, 520, "B", dict(pruning_min_kpts=64)),
+                                 (1024, 1024, "A", dict(depth_confidence=-1, width_confidence=-1))):
+        sd = synth.make_state_dict(0, recipe=recipe)
+        data = gpu_util.to_torch(synth.make_batch(23, 2, n0, n1))
+        model = gpu_util.make_model(sd, precision, **kw)
+        base = model(data)
+        for rows in (64, 16):
+            model.set_option("attn_rows", rows)
+            other = model(data)
+            for key in ("matches0", "matches1", "matching_scores0", "matching_scores1", "prune0", "prune1"):
+                assert torch.equal(base[key], other[key]), (n0, n1, rows, key)
+        model.set_option("attn_rows", 32)
+
+
 @pytest.mark.parametrize("variant", [1, 2])
 def test_streaming_tail_variants_match_golden(variant):
     """lg_tail4.hip: <4 waves x 64 rows> and <8 waves x 128 rows> decompositions of the fused tail (engine option

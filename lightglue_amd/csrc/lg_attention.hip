@@ -58,7 +58,7 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
     constexpr int NC = 64 / (4 * EPC);            // chunks along a 64-long contraction (2 or 4)
     constexpr int NCT = 64 * SLOTS / ATHREADS;    // staged chunks per thread per tile (2 or 4)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* smK = smem;
+    char* smK = smem;                 // buffer b: K at smK + b * BUFB, V^T at smV + b * BUFB (BUFB = both tiles)
     char* smV = smem + 64 * ROWB;
 
     // XCD-aware order: the query tiles of one (segment, head) share its K/V (<= 1 MB at n = 4096), so keep
@@ -127,13 +127,15 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
             rv[i] = *reinterpret_cast<const u32x4*>(Vt + ((long long)head * 64 + row) * R + kvbase + kv0 + slot * EPC);
         }
     };
-    auto store_tile = [&](int kv0) {
+    constexpr int BUFB = 2 * 64 * ROWB;   // one K + V^T tile pair (a single buffer is used; see DESIGN.md for the double-buffered variants that lost)
+    auto store_tile = [&](int buf, int kv0) {
+        char* bK = smK + buf * BUFB; char* bV = smV + buf * BUFB;
         if (kv0 + ABK <= kvlen) {   // wave-uniform fast path: every key of the tile is live
 #pragma unroll
             for (int i = 0; i < NCT; ++i) {
                 const int c = tid + ATHREADS * i, row = c / SLOTS, slot = c % SLOTS;
-                *reinterpret_cast<u32x4*>(smK + k_off<ROWB>(row, slot)) = rk[i];
-                *reinterpret_cast<u32x4*>(smV + lds_off<ROWB>(row, slot)) = rv[i];
+                *reinterpret_cast<u32x4*>(bK + k_off<ROWB>(row, slot)) = rk[i];
+                *reinterpret_cast<u32x4*>(bV + lds_off<ROWB>(row, slot)) = rv[i];
             }
         } else {
 #pragma unroll
@@ -142,8 +144,8 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
                 // rows/keys past the live length may hold anything (uninitialised workspace): zero them so
                 // that 0-probabilities never multiply a NaN
                 const u32x4 kz = (kv0 + row < kvlen) ? rk[i] : u32x4{0u, 0u, 0u, 0u};
-                *reinterpret_cast<u32x4*>(smK + k_off<ROWB>(row, slot)) = kz;
-                *reinterpret_cast<u32x4*>(smV + lds_off<ROWB>(row, slot)) = mask_tail<Tag>(rv[i], kvlen - (kv0 + slot * EPC));
+                *reinterpret_cast<u32x4*>(bK + k_off<ROWB>(row, slot)) = kz;
+                *reinterpret_cast<u32x4*>(bV + lds_off<ROWB>(row, slot)) = mask_tail<Tag>(rv[i], kvlen - (kv0 + slot * EPC));
             }
         }
     };
@@ -155,19 +157,9 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
 #else
 #define ATT_TICK(slot) do { } while (0)
 #endif
-    load_tile(0);
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int kv0 = tile * ABK;
-        __syncthreads();
-        ATT_TICK(0);
-        store_tile(kv0);
-        __syncthreads();
-        ATT_TICK(1);
-        load_tile(tile + 1 < ntiles ? kv0 + ABK : kv0);   // clamped, not branched (keeps hipcc's vmcnt counting exact)
-        __builtin_amdgcn_sched_barrier(0);                // and pinned ahead of the MFMAs
-
-        // ---- S^T = K Q^T  (4 key tiles x 2 query tiles)
-        f32x4 s[4][QT];
+    // ---- S^T = K Q^T  (4 key tiles x QT query tiles) from the K tile in LDS buffer `buf`
+    auto qk = [&](int buf, f32x4 (&s)[4][QT]) {
+        const char* bK = smK + buf * BUFB;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -177,14 +169,15 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 const int krow = EPC == 8 ? 32 * (kt >> 1) + 8 * (lr >> 2) + 4 * (kt & 1) + (lr & 3) : kt * 16 + lr;
-                const u32x4 kf = *reinterpret_cast<const u32x4*>(smK + k_off<ROWB>(krow, c * 4 + g));
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(bK + k_off<ROWB>(krow, c * 4 + g));
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(s[kt][qt], kf, qf[qt][c]);
             }
         }
-        ATT_TICK(2);
-        // ---- online softmax (fp32), per query column.  Only the last tile can hold dead keys.
-        if (kv0 + ABK > kvlen) {   // wave-uniform
+    };
+    // ---- online softmax (fp32) of one tile's scores, per query column; s becomes the probabilities
+    auto smax_rescale = [&](f32x4 (&s)[4][QT], int kv0) {
+        if (kv0 + ABK > kvlen) {   // wave-uniform: only the last tile can hold dead keys
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
@@ -206,13 +199,12 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
             m_new[qt] = vmax2(m_run[qt], mx * a.scale_log2e);   // finite: every tile holds >= 1 live key (scale > 0)
             grew = grew || (m_new[qt] > m_run[qt] + 8.f);
         }
-        ATT_TICK(3);
-        // Deferred rescale (guide T13): keep the stale running maximum while no row's maximum grew by more than
-        // DEFER_LOG2 (base-2 units) — probabilities then reach at most 2^8 instead of 1, which costs nothing in the fp32
-        // l / O accumulators and nothing relative in the f16 / bf16 P operand.  Order is the textbook one: decide,
-        // rescale o and l, THEN exponentiate this tile against the (possibly updated) maximum.  The first tile always
-        // takes the branch (m_run = -inf); on most later tiles the O accumulators are not touched by the VALU at all.
-        if (__any(grew)) {   // threshold 2^8: see `grew` above
+        // Deferred rescale (guide T13): keep the stale running maximum while no row's maximum grew by more than 2^8
+        // (base-2 units) — probabilities then reach at most 2^8 instead of 1, which costs nothing in the fp32 l / O
+        // accumulators and nothing relative in the f16 / bf16 P operand.  Order is the textbook one: decide, rescale o
+        // and l, THEN exponentiate this tile against the (possibly updated) maximum.  The first tile always takes the
+        // branch (m_run = -inf); on most later tiles the O accumulators are not touched by the VALU at all.
+        if (__any(grew)) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new[qt]);
@@ -222,6 +214,8 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
                 m_run[qt] = m_new[qt];
             }
         }
+    };
+    auto sexp = [&](f32x4 (&s)[4][QT]) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             // exp2(s*c - m): packed fma (two scores per v_pk_fma_f32) + the bare v_exp_f32 (arguments <= 8, flush-to-zero tail
@@ -237,11 +231,12 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
                     s[kt][qt][h] = p[0]; s[kt][qt][h + 1] = p[1];
                     rs2 += p;
                 }
-            const float rs = rs2[0] + rs2[1];
-            l_run[qt] += rs;
+            l_run[qt] += rs2[0] + rs2[1];
         }
-        ATT_TICK(4);
-        // ---- O^T += V^T P^T
+    };
+    // ---- O^T += V^T P^T with the V^T tile in LDS buffer `buf`
+    auto pv = [&](int buf, f32x4 (&s)[4][QT]) {
+        const char* bV = smV + buf * BUFB;
         if constexpr (EPC == 8) {
 #pragma unroll
             for (int tp = 0; tp < 2; ++tp) {
@@ -250,7 +245,7 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
                 for (int qt = 0; qt < QT; ++qt) pp[qt] = pack8<Tag>(s[2 * tp][qt], s[2 * tp + 1][qt]);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    const u32x4 vf = *reinterpret_cast<const u32x4*>(smV + lds_off<ROWB>(dt * 16 + lr, 4 * tp + g));   // keys 32tp + 8g .. +7
+                    const u32x4 vf = *reinterpret_cast<const u32x4*>(bV + lds_off<ROWB>(dt * 16 + lr, 4 * tp + g));   // keys 32tp + 8g .. +7
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(o[dt][qt], vf, pp[qt]);
                 }
@@ -260,13 +255,34 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
             for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    const u32x4 vf = *reinterpret_cast<const u32x4*>(smV + lds_off<ROWB>(dt * 16 + lr, 4 * kt + g));
+                    const u32x4 vf = *reinterpret_cast<const u32x4*>(bV + lds_off<ROWB>(dt * 16 + lr, 4 * kt + g));
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(o[dt][qt], vf, __builtin_bit_cast(u32x4, s[kt][qt]));
                 }
             }
         }
-        ATT_TICK(5);
+    };
+
+    load_tile(0);
+    {
+        f32x4 s[4][QT];
+        for (int tile = 0; tile < ntiles; ++tile) {
+            const int kv0 = tile * ABK;
+            __syncthreads();
+            ATT_TICK(0);
+            store_tile(0, kv0);
+            __syncthreads();
+            ATT_TICK(1);
+            load_tile(tile + 1 < ntiles ? kv0 + ABK : kv0);   // clamped, not branched (keeps hipcc's vmcnt counting exact)
+            __builtin_amdgcn_sched_barrier(0);                // and pinned ahead of the MFMAs
+            qk(0, s);
+            ATT_TICK(2);
+            smax_rescale(s, kv0);
+            sexp(s);
+            ATT_TICK(4);
+            pv(0, s);
+            ATT_TICK(5);
+        }
     }
 #ifdef LG_ATTN_TIMING
     if (a.dbg && lane == 0) {

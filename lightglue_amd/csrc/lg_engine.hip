@@ -709,7 +709,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                     proj_done = true;
                 }
                 TRY(prof_begin(e, PC_TAIL, s));
-                HIPCHK(e->tail_variant == 1 ? launch_tail4(prec, ta, s) : e->tail_variant == 2 ? launch_tail128(prec, ta, s) : launch_tail(prec, ap, ta, s));
+                HIPCHK(e->tail_variant == 1 ? launch_tail4(prec, ta, s) : e->tail_variant == 2 ? launch_tail128(prec, ta, s) : e->tail_variant == 3 ? launch_tail32(prec, ta, s) : launch_tail(prec, ap, ta, s));
                 TRY(prof_end(e, s));
                 STEP_DONE(); STEP_DONE(); STEP_DONE(); STEP_DONE();
                 continue;

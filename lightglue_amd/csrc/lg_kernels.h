@@ -74,6 +74,7 @@ bool launch_tail_supports_next(int prec, int attn_prec);
 hipError_t launch_tail(int prec, int attn_prec, const TailArgs& a, hipStream_t s);    // 8 waves, one workgroup per CU (lg_tail.hip)
 hipError_t launch_tail4(int prec, const TailArgs& a, hipStream_t s);   // 4 waves x 64 rows, two workgroups per CU (lg_tail4.hip)
 hipError_t launch_tail128(int prec, const TailArgs& a, hipStream_t s); // 8 waves x 128 rows: half the weight stream per row (lg_tail4.hip)
+hipError_t launch_tail32(int prec, const TailArgs& a, hipStream_t s);  // 4 waves x 32 rows: twice the workgroups, for under-filled grids (lg_tail4.hip)
 
 // ---------------------------------------------------------------- attention (lg_attention.hip)
 struct AttnArgs {

@@ -398,5 +398,7 @@ template <int NW, int MT> static hipError_t launch_tailx_p(int prec, const TailA
 }
 hipError_t launch_tail4(int prec, const TailArgs& a, hipStream_t s) { return launch_tailx_p<4, 4>(prec, a, s); }
 hipError_t launch_tail128(int prec, const TailArgs& a, hipStream_t s) { return launch_tailx_p<8, 8>(prec, a, s); }
+// 32 rows per workgroup, 4 waves: twice the workgroups of the default — for grids that do not fill the chip (small batches)
+hipError_t launch_tail32(int prec, const TailArgs& a, hipStream_t s) { return launch_tailx_p<4, 2>(prec, a, s); }
 
 }  // namespace lg

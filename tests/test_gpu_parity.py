@@ -303,7 +303,7 @@ def test_attention_rows_per_wave_variants_are_equivalent(precision):
         model.set_option("attn_rows", 32)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_streaming_tail_variants_match_golden(variant):
     """lg_tail4.hip: <4 waves x 64 rows> and <8 waves x 128 rows> decompositions of the fused tail (engine option
     tail_variant) are kept correct even though the default (lg_tail.hip) is the fastest."""

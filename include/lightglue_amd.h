@@ -106,12 +106,17 @@ int lg_engine_reserve(lg_engine* e, int32_t max_batch, int32_t max_n0, int32_t m
  * Asynchronous: no host synchronisation when the workspace is already large enough. */
 int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream);
 
-/* Engine options.  "fused_tail" (default 1): run out_proj + ffn + LayerNorm + GELU + residual as one kernel
- * (lg_tail.hip); "fused_proj" (default 1): the full-width q/k/v projection kernel (lg_proj.hip).  0 selects the
- * generic per-op GEMM kernels (kept for stage-by-stage parity tests).  "fused_next" (default 1): the tail kernel also
- * runs the NEXT block's q/k/v projection on the x tile it has just produced (bit-identical to the separate kernel;
- * needs fused_tail and fused_proj, 16-bit operand precisions).  "profile_only" (default -1): restrict the HIP-event
- * timing of lg_engine_profile_enable to one kernel class (index of lg_profile_class_name), -1 = all classes. */
+/* Engine options (defaults are the product configuration; the others exist for tests, A/B measurements and profiling):
+ *   "fused_tail"   1  out_proj + ffn + LayerNorm + GELU + residual as one kernel (lg_tail.hip); 0 = per-op GEMM kernels
+ *   "fused_proj"   1  full-width q/k/v projection kernel (lg_proj.hip); 0 = generic GEMM with the QKV epilogue
+ *   "fused_next"   1  the tail kernel also runs the NEXT block's q/k/v projection on the x tile it has just produced
+ *                     (bit-identical to the separate kernel; needs fused_tail, fused_proj and 16-bit operand precisions)
+ *   "tail_variant" 0  0 = lg_tail.hip; lg_tail4.hip decompositions: 1 = 4 waves x 64 rows, 2 = 8 waves x 128 rows,
+ *                     3 = 4 waves x 32 rows (all correct, none faster; env LG_TAIL_VARIANT)
+ *   "attn_rows"    32 query rows per attention wave: 16 | 32 | 64 (bit-identical outputs; env LG_ATTN_ROWS)
+ *   "profile_only" -1 restrict the HIP-event timing of lg_engine_profile_enable to one kernel class (index of
+ *                     lg_profile_class_name), -1 = all classes
+ *   "tail_timing"  0  shader-clock taps: 1 tail kernel, 2 self projection, 3 attention (LG_ATTN_TIMING builds), 4 LSE sweep */
 int lg_engine_set_option(lg_engine* e, const char* key, int32_t value);
 
 /* ---- test / profiling taps (not used by the product path) ---- */

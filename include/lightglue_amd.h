@@ -116,7 +116,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream);
  *   "attn_rows"    32 query rows per attention wave: 16 | 32 | 64 (bit-identical outputs; env LG_ATTN_ROWS)
  *   "profile_only" -1 restrict the HIP-event timing of lg_engine_profile_enable to one kernel class (index of
  *                     lg_profile_class_name), -1 = all classes
- *   "tail_timing"  0  shader-clock taps: 1 tail kernel, 2 self projection, 3 attention (LG_ATTN_TIMING builds), 4 LSE sweep */
+ *   "tail_timing"  0  shader-clock taps: 1 tail kernel, 2 self projection, 3 attention (LG_ATTN_TIMING builds) */
 int lg_engine_set_option(lg_engine* e, const char* key, int32_t value);
 
 /* ---- test / profiling taps (not used by the product path) ---- */

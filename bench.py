@@ -70,6 +70,10 @@ PMC_TRAFFIC_BYTES = {("bf16x3", 32, 1024, "fused_tail"): (2 * 1.199e5 + 6.554e4)
                                                                + (2 * 1.199e5 + 6.554e4)) / 18 * 1024}
 
 
+# the two log-assignment sweeps (profiles/r01f_pmc_{fetch,write}.md): 2 x FETCH_SIZE + WRITE_SIZE of lse_sweep + argmax_sweep
+PMC_TRAFFIC_ASSIGN = {("bf16x3", 32, 1024): (2 * 6.556e4 + 8320 + 2 * 6.671e4 + 8448) * 1024}
+
+
 def hbm_bytes_assign(pairs: int, n: int, m: int) -> float:
     """two fp32 read sweeps of the similarity matrix (row/column LSE, then score/argmax)."""
     return pairs * 8.0 * n * m
@@ -250,7 +254,8 @@ def main():
                               "achieved": hbm_bytes_assign(B, n, m) / (timed["assign"][0] / timed["assign"][1] * 1e-3) / 1e9,
                               "peak": 8000.0, "unit": "GB/s",
                               "frac": hbm_bytes_assign(B, n, m) / (timed["assign"][0] / timed["assign"][1] * 1e-3) / 1e9 / 8000.0,
-                              "algorithmic_bytes_per_launch": hbm_bytes_assign(B, n, m)} if "assign" in timed else None),
+                              "algorithmic_bytes_per_launch": hbm_bytes_assign(B, n, m),
+                              "traffic": PMC_TRAFFIC_ASSIGN.get((args.precision, B, n))} if "assign" in timed else None),
             "kernel_ms_per_step": kernel_ms,
             "kernel_ms_per_step_source": ("HIP events around every launch during the warm-up steps; the roofline kernel's entry and "
                                           "avg_launch_ms come from events inside the timed region") if warm_prof else "HIP events inside the timed region",

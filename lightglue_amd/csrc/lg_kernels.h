@@ -66,6 +66,7 @@ struct TailArgs {
     const float* gamma; const float* beta;   // LayerNorm(512)
     const void* W2; const float* b2;         // [256][512] fragment-packed, [256]
     long long* dbg;                          // profiling tap: [blocks][8 waves][8] shader-clock stamps, or nullptr
+    int* stag; int stag_delay;               // experiment (lg_tail4.hip): per-CU arrival counters [2048] + start delay (100 MHz ticks) of a CU's 2nd workgroup
     // optional: the NEXT block's q/k/v projection, run on the x tile this kernel has just produced (next.W == nullptr:
     // none).  next.X is unused; supported for 16-bit operand / attention precisions (launch_tail_supports_next).
     ProjArgs next;

@@ -7,9 +7,8 @@
 // split the columns; the 64 x 256 activation tile is read from HBM exactly once, converted to the operand
 // precision and kept in LDS (64 KB as split bf16); weight fragments come pre-packed in MFMA order straight
 // from L2 (one coalesced 1 KB wave load each).  Wave w owns the n-tiles {w + 8j}: the columns are produced in
-// two passes of NTP n-tiles per wave (keeps accumulators + weight ring under the register budget) and each
-// pass's 64 x (NTP*128) output tile is staged through LDS so that q/k rows leave as full 128-byte lines and
-// v^T as 64-row lines (a head's 64 rows are contiguous in both layouts -> 8 KB contiguous stores).
+// two passes of NTP n-tiles per wave (keeps accumulators + weight ring under the register budget); the outputs
+// leave straight from the accumulators (lg_proj_body.h: transposed MFMA form for q/k, plain form for v^T).
 #include "lg_proj_body.h"
 
 namespace lg {
@@ -22,8 +21,6 @@ __global__ __launch_bounds__(PTHREADS) void proj_kernel(ProjArgs a) {
     constexpr int NV = EPC / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* smA = smem;                                              // [NPART][STAGES][64][128 B]
-    char* smO = smem + PJL<PREC>::A_BYTES;                         // [NHC][64 lines][LINE]
-    float* smCS = reinterpret_cast<float*>(smO + PJO<TA, NTP>::O_BYTES);   // rotary tables of the tile: cos [64][32], sin [64][32]
 
     const TileLoc t = locate_tile(a.rs, blockIdx.x, PBM);
     if (t.r0 >= a.rs.len[t.seg]) return;
@@ -31,15 +28,6 @@ __global__ __launch_bounds__(PTHREADS) void proj_kernel(ProjArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8] = clock64();   // profiling tap, slot 0
 
-    // ---- rotary tables of the tile -> LDS (two coalesced 16-byte loads per thread; the epilogue used to issue
-    //      ~100 dependent 4-byte global loads per lane for them, 45 % of the kernel)
-    if (a.cosb != nullptr) {
-        const int i = tid;                      // 512 threads x float4 = 64 rows x 32 floats
-        const f32x4 c4 = *reinterpret_cast<const f32x4*>(a.cosb + (long long)t.grow0 * 32 + i * 4);
-        const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.sinb + (long long)t.grow0 * 32 + i * 4);
-        *reinterpret_cast<f32x4*>(smCS + i * 4) = c4;
-        *reinterpret_cast<f32x4*>(smCS + 2048 + i * 4) = s4;
-    }
     // ---- activation tile: HBM -> registers -> operand precision -> LDS (once)
     {
         const int srow = tid >> 3, sslot = tid & 7;
@@ -65,12 +53,12 @@ __global__ __launch_bounds__(PTHREADS) void proj_kernel(ProjArgs a) {
             }
         }
     }
-    proj_compute<PREC, TA, NTP, NPASS>(a, t, smA, smO, smCS, 0);
+    proj_compute<PREC, TA, NTP, NPASS>(a, t, smA, 0);
 }
 
 template <int PREC, class TA, int NTP, int NPASS> static hipError_t launch_proj_t(const ProjArgs& a, hipStream_t s) {
     const int R = a.rs.B * (a.rs.cap0 + a.rs.cap1);
-    constexpr int smem = PJL<PREC>::A_BYTES + PJO<TA, NTP>::O_BYTES + PJ_CS_BYTES;
+    constexpr int smem = PJL<PREC>::A_BYTES;
     auto kern = proj_kernel<PREC, TA, NTP, NPASS>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
@@ -78,11 +66,8 @@ template <int PREC, class TA, int NTP, int NPASS> static hipError_t launch_proj_
     return hipGetLastError();
 }
 template <int PREC, class TA> static hipError_t launch_proj_n(const ProjArgs& a, hipStream_t s) {
-    if (a.Nout == 768) {
-        if constexpr (sizeof(TA) == 4) return launch_proj_t<PREC, TA, 2, 3>(a, s);
-        else return launch_proj_t<PREC, TA, 3, 2>(a, s);
-    }
-    if (a.Nout == 512) return launch_proj_t<PREC, TA, 2, 2>(a, s);
+    if (a.Nout == 768 && a.n_qk_groups == 2 && a.cosb && a.sinb) return launch_proj_t<PREC, TA, 3, 2>(a, s);
+    if (a.Nout == 512 && a.n_qk_groups == 1) return launch_proj_t<PREC, TA, 2, 2>(a, s);
     return hipErrorInvalidValue;
 }
 template <int PREC> static hipError_t launch_proj_p(int attn_prec, const ProjArgs& a, hipStream_t s) {

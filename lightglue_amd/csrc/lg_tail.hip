@@ -9,25 +9,31 @@
 // Algebra: ffn.0([x ; Wo ctx + bo]) = [W1x | W1m Wo] [x ; ctx] + (b1 + W1m bo): the out_proj GEMM is folded
 // into the first FFN matrix on the host (in double precision) — "Wcat" [512 x 512], "bcat" [512].
 //
-// Workgroup = 64 keypoint rows, 512 threads = 8 waves; wave w owns output columns [64w, 64w+64) of the
-// hidden layer and [32w, 32w+32) of the output.  The A operand (activations) is shared by all waves
-// through LDS; every wave needs a DIFFERENT slice of the weights, so weights are never staged in LDS:
-// they are pre-packed on the host in MFMA-fragment order and each B fragment is one fully coalesced
-// 1 KB wave load straight from L2 into registers (weights are ~2.3 MB per precision plane set and stay
-// L2-resident).
+// Workgroup = 64 keypoint rows, 512 threads = 8 waves; wave w owns output columns {w + 8j} x 16 of the
+// hidden layer and [32w, 32w+32) of the output.  The activations are shared by all waves through LDS; every
+// wave needs a DIFFERENT slice of the weights, so weights are never staged in LDS: they are pre-packed on the
+// host in MFMA-fragment order and each fragment is one fully coalesced 1 KB wave load straight from L2 into
+// registers (the weights of a block stay L2-resident; measured L2 -> VGPR ceiling of this pattern: ~50 B/clk/CU).
+//
+// EVERY product is computed TRANSPOSED, C^T = W a^T (weight fragment = A operand, activation fragment = B operand;
+// the two operand layouts of v_mfma_f32_16x16x32 are symmetric, so LDS tiles and packed weights are the same as for
+// the plain form).  Lane (lr, g) of a 16x16 tile then holds keypoint ROW lr and the 4 CONSECUTIVE columns 4g..4g+3:
+//   * a row's LayerNorm partial is 16 in-lane adds + 2 cross-lane steps (plain form: 16 values x 4 DPP steps),
+//   * bias / gamma / beta arrive as one float4 per tile,
+//   * GELU output, residual and the next projection's activation tile are 8/16-byte accesses of 4 consecutive
+//     elements of one row: no lane-pair transposition, no staging of the output tile through LDS.
 //   phase A  h = [x ; ctx] Wcat^T + bcat.  The whole 64 x 512 activation tile lives in LDS (128 KB as split
 //            bf16): the x half is loaded/converted first, the ctx half is fetched while the x half is being
 //            multiplied -> two barriers for the whole phase, weight fragments prefetched from L2 on a ring.
-//            Wave w owns the n-tiles {w, w+8, w+16, w+24} (16 hidden units each).
-//   LN       two-pass row statistics across the 8 waves (LDS scratch), in registers
+//   LN       per-wave (mean, M2) over its 64 hidden units in registers, ONE exchange through LDS, merged with the
+//            parallel-variance formula (exactly a two-pass variance; one barrier pair instead of two)
 //   phase B  out = g W2^T + b2 in 4 steps: step j multiplies K-stages 2j, 2j+1 of g (128 hidden units), then the
-//            wave applies GELU to its next n-tile and writes it to LDS in A-operand order (one barrier per step).
-//            (Running the two halves of the workgroup in opposite MFMA/GELU order to overlap the pipes was
-//            measured and lost 8k cycles per workgroup; see DESIGN.md.)
-//   epilogue out tile staged through LDS, residual add and store as full 1 KB rows
-//   next     (optional, NEXT != 0) the new x tile is ALSO written to LDS in operand precision and the NEXT block's
-//            q/k/v projection (lg_proj_body.h; SelfBlock -> this layer's CrossBlock, CrossBlock -> next layer's
-//            SelfBlock) runs here: saves that kernel's launch, its x-tile read + conversion and one grid drain.
+//            wave applies GELU to its next n-tile and writes it to LDS as 8-byte pieces (one barrier per step).
+//   epilogue residual add and x store straight from the accumulators (16 bytes per lane, 64 contiguous bytes per row)
+//   next     (optional, NEXT != 0) the new x tile is ALSO written to LDS in operand precision — into K-stages 0..3 of
+//            the g planes, which are dead once every wave has entered step 3, so no barrier is needed in front of it —
+//            and the NEXT block's q/k/v projection (lg_proj_body.h; SelfBlock -> this layer's CrossBlock, CrossBlock ->
+//            next layer's SelfBlock) runs here: saves that kernel's launch, its x-tile read + conversion and a grid drain.
 #include "lg_proj_body.h"
 
 namespace lg {
@@ -47,7 +53,7 @@ template <int PREC> struct TL {
     static constexpr int TILE = TBM * 128;                          // one plane of one stage: 64 rows x 128 B
     static constexpr int G_PLANE = STAGES * TILE;                   // 64 KB (16-bit) / 128 KB (f32)
     static constexpr int G_BYTES = TT<PREC>::NPART * G_PLANE;
-    static constexpr int RED_BYTES = 8 * TBM * 4;
+    static constexpr int RED_BYTES = 8 * TBM * 8;                   // (mean, M2) per row per wave
     static constexpr int TOTAL = G_BYTES + RED_BYTES;
 };
 
@@ -77,20 +83,18 @@ __device__ __forceinline__ f32x2 gelu_fast2(f32x2 u) {
     return half_u + half_u * sgn;
 }
 
+// acc (C^T tile) += w x^T for one k-chunk; split-bf16: (w_hi x_lo) + (w_lo x_hi) + (w_hi x_hi)
 template <int PREC>
-__device__ __forceinline__ void tail_mma(f32x4& acc, const u32x4* a, const u32x4* b) {
+__device__ __forceinline__ void tail_mma(f32x4& acc, const u32x4* wf, const u32x4* xf) {
     typedef typename TT<PREC>::Tag Tag;
     if constexpr (TT<PREC>::NPART == 2) {
-        mma_chunk<Tag>(acc, a[1], b[0]);   // lo * hi
-        mma_chunk<Tag>(acc, a[0], b[1]);   // hi * lo
-        mma_chunk<Tag>(acc, a[0], b[0]);   // hi * hi
+        mma_chunk<Tag>(acc, wf[0], xf[1]);   // hi * lo
+        mma_chunk<Tag>(acc, wf[1], xf[0]);   // lo * hi
+        mma_chunk<Tag>(acc, wf[0], xf[0]);   // hi * hi
     } else {
-        mma_chunk<Tag>(acc, a[0], b[0]);
+        mma_chunk<Tag>(acc, wf[0], xf[0]);
     }
 }
-
-constexpr int OT_LD = 260;                       // padded row stride (floats) of the staged fp32 output tile
-constexpr int OT_BYTES = TBM * OT_LD * 4;        // 66 560
 
 // NEXT: 0 = plain tail, 1 = + SelfBlock projection of the next layer (768 columns, rotary), 2 = + CrossBlock
 // projection (512 columns).  TA = element type of q/k/v (attention operand precision), only read when NEXT != 0.
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) tail_mma<PREC>(acc[mt][nt], af[mt], b[nt]);
+            for (int nt = 0; nt < 4; ++nt) tail_mma<PREC>(acc[mt][nt], b[nt], af[mt]);
     };
     load_half(0);
 #pragma unroll
@@ -213,111 +217,81 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         }
     }
     stamp(1);
-    // ------------------------------------------------------------------ bias + LayerNorm(512) + GELU
+    // ------------------------------------------------------------------ bias + LayerNorm(512)
+    // acc[mt][nt][r] = h[row mt*16 + lr][hidden (w + 8 nt)*16 + 4g + r]
     {
-        float bias[4], gam[4], bet[4];
+        f32x4 gam[4], bet[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const int col = (w + 8 * nt) * 16 + lr;
-            bias[nt] = a.bcat[col]; gam[nt] = a.gamma[col]; bet[nt] = a.beta[col];
+            const int col = (w + 8 * nt) * 16 + 4 * g;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bcat + col);
+            gam[nt] = *reinterpret_cast<const f32x4*>(a.gamma + col); bet[nt] = *reinterpret_cast<const f32x4*>(a.beta + col);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] += b4;
         }
-        float part[4][4];   // [mt][r] partial sums over this lane's 4 columns
+        // this wave's 64 hidden units of row (mt, lr): local mean and M2 = sum (h - mean)^2, entirely in registers
+        f32x2* red2 = reinterpret_cast<f32x2*>(red);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 4; ++mt) {
+            float sacc = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float sacc = 0.f;
+            for (int nt = 0; nt < 4; ++nt) sacc += (acc[mt][nt][0] + acc[mt][nt][1]) + (acc[mt][nt][2] + acc[mt][nt][3]);
+            sacc = xor32_sum(xor16_sum(sacc));
+            const float ml = sacc * (1.f / 64.f);
+            float q = 0.f;
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) { acc[mt][nt][r] += bias[nt]; sacc += acc[mt][nt][r]; }
-                part[mt][r] = sacc;
-            }
-        auto block_row_sum = [&](float (&p)[4][4]) {   // p[mt][r] -> sum over all 512 columns of row mt*16+4g+r
+            for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+                for (int r = 0; r < 4; ++r) { const float d = acc[mt][nt][r] - ml; q += d * d; }
+            q = xor32_sum(xor16_sum(q));
+            if (g == 0) red2[(mt * 16 + lr) * 8 + w] = f32x2{ml, q};
+        }
+        __syncthreads();   // also: every wave is past its last read of the activation tile -> g may overwrite it below
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    p[mt][r] = row16_sum(p[mt][r]);
-                }
-            __syncthreads();   // previous users of `red` (and, first time, of the staging buffers) are done
-            if (lr == 0) {
+        for (int mt = 0; mt < 4; ++mt) {
+            // merge the 8 (count 64, mean, M2) triples of the row: mean = avg(mean_w), M2 = sum M2_w + 64 sum (mean_w - mean)^2
+            const f32x4* pr = reinterpret_cast<const f32x4*>(red2 + (mt * 16 + lr) * 8);
+            const f32x4 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
+            const float mean = (((p0[0] + p0[2]) + (p1[0] + p1[2])) + ((p2[0] + p2[2]) + (p3[0] + p3[2]))) * 0.125f;
+            float m2 = ((p0[1] + p0[3]) + (p1[1] + p1[3])) + ((p2[1] + p2[3]) + (p3[1] + p3[3]));
+            float dm = 0.f;
+            { float d;
+              d = p0[0] - mean; dm += d * d; d = p0[2] - mean; dm += d * d; d = p1[0] - mean; dm += d * d; d = p1[2] - mean; dm += d * d;
+              d = p2[0] - mean; dm += d * d; d = p2[2] - mean; dm += d * d; d = p3[0] - mean; dm += d * d; d = p3[2] - mean; dm += d * d; }
+            m2 += 64.f * dm;
+            const float rstd = __builtin_amdgcn_rsqf(m2 * (1.f / 512.f) + 1e-5f);   // v_rsq_f32, 1 ulp
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+            for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) red[w * TBM + mt * 16 + g * 4 + r] = p[mt][r];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {   // rows 4g..4g+3 of tile mt are contiguous: one 16-byte read per wave slot
-                f32x4 v = *reinterpret_cast<const f32x4*>(red + mt * 16 + g * 4);
-#pragma unroll
-                for (int ww = 1; ww < 8; ++ww) v += *reinterpret_cast<const f32x4*>(red + ww * TBM + mt * 16 + g * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) p[mt][r] = v[r];
-            }
-        };
-        block_row_sum(part);
-        float mean[4][4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                mean[mt][r] = part[mt][r] * (1.f / 512.f);
-                float sq = 0.f;
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) { const float d = acc[mt][nt][r] - mean[mt][r]; acc[mt][nt][r] = d; sq += d * d; }
-                part[mt][r] = sq;
-            }
-        block_row_sum(part);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float rstd = __builtin_amdgcn_rsqf(part[mt][r] * (1.f / 512.f) + 1e-5f);   // v_rsq_f32, 1 ulp
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt][r] = acc[mt][nt][r] * rstd * gam[nt] + bet[nt];   // pre-GELU
-            }
+                for (int r = 0; r < 4; ++r) acc[mt][nt][r] = (acc[mt][nt][r] - mean) * rstd * gam[nt][r] + bet[nt][r];   // pre-GELU
+        }
     }
     stamp(2);
-    // ------------------------------------------------------------------ GELU + g -> LDS (A-operand order) + phase B
-    // n-tile j of wave w = hidden units [(w + 8j)*16, +16) = K-stage 2j + (w >> 2), columns (w & 3)*16 + lr of it.
+    // ------------------------------------------------------------------ GELU + g -> LDS (B-operand tiles) + phase B
+    // n-tile j of wave w = hidden units [(w + 8j)*16, +16) = K-stage 2j + (w >> 2), columns (w & 3)*16 + 4g + r of it:
+    // a lane's 4 values are 4 consecutive k of one row = one 8-byte piece per plane (f32: one 16-byte piece).
     auto gelu_store = [&](int j) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            f32x2 v01 = gelu_fast2(f32x2{acc[mt][j][0], acc[mt][j][1]});
-            f32x2 v23 = gelu_fast2(f32x2{acc[mt][j][2], acc[mt][j][3]});
-            const float gv[4] = {v01[0], v01[1], v23[0], v23[1]};
+            const f32x2 v01 = gelu_fast2(f32x2{acc[mt][j][0], acc[mt][j][1]});
+            const f32x2 v23 = gelu_fast2(f32x2{acc[mt][j][2], acc[mt][j][3]});
+            const int row = mt * 16 + lr;
             if constexpr (EPC == 8) {
-                char* tile0 = smem + (2 * j + (w >> 2)) * TILE;
-#pragma unroll
-                for (int rp = 0; rp < 4; rp += 2) {
-                    // even lanes write row rp, odd lanes row rp+1; each writes the (even col, odd col) pair
-                    const bool odd = lr & 1;
-                    const float mine = odd ? gv[rp + 1] : gv[rp];
-                    const float give = odd ? gv[rp] : gv[rp + 1];
-                    const float got = dpp_xor1(give);
-                    const float c0 = odd ? got : mine, c1 = odd ? mine : got;   // values at (even col, odd col)
-                    const int row = mt * 16 + g * 4 + rp + (odd ? 1 : 0);
-                    const int col = (w & 3) * 16 + (lr & ~1);
-                    const int off = lds_off<128>(row, col >> 3) + (col & 7) * 2;
-                    if constexpr (PREC == PREC_BF16X3) {
-                        const float h0 = bf16_round(c0), h1 = bf16_round(c1);
-                        *reinterpret_cast<uint32_t*>(tile0 + off) = pack2_bf16(h0, h1);
-                        *reinterpret_cast<uint32_t*>(tile0 + G_PLANE + off) = pack2_bf16(c0 - h0, c1 - h1);
-                    } else {
-                        *reinterpret_cast<uint32_t*>(tile0 + off) = pack2<Tag>(c0, c1);
-                    }
+                char* dst = smem + (2 * j + (w >> 2)) * TILE + lds_off<128>(row, (w & 3) * 2 + (g >> 1)) + (g & 1) * 8;
+                if constexpr (PREC == PREC_BF16X3) {
+                    const float h0 = bf16_round(v01[0]), h1 = bf16_round(v01[1]), h2 = bf16_round(v23[0]), h3 = bf16_round(v23[1]);
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{pack2_bf16(h0, h1), pack2_bf16(h2, h3)};
+                    *reinterpret_cast<u32x2*>(dst + G_PLANE) = u32x2{pack2_bf16(v01[0] - h0, v01[1] - h1), pack2_bf16(v23[0] - h2, v23[1] - h3)};
+                } else {
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<Tag>(v01[0], v01[1]), pack2<Tag>(v23[0], v23[1])};
                 }
             } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int hcol = (w + 8 * j) * 16 + lr, row = mt * 16 + g * 4 + r;   // f32: K-stage = 32 hidden units
-                    char* tile = smem + (hcol >> 5) * TILE;
-                    *reinterpret_cast<float*>(tile + lds_off<128>(row, (hcol & 31) >> 2) + (hcol & 3) * 4) = gv[r];
-                }
+                const int hcol = (w + 8 * j) * 16 + 4 * g;   // f32: K-stage = 32 hidden units
+                *reinterpret_cast<f32x4*>(smem + (hcol >> 5) * TILE + lds_off<128>(row, (hcol & 31) >> 2)) = f32x4{v01[0], v01[1], v23[0], v23[1]};
             }
         }
     };
-    // all waves passed the barriers of the last block_row_sum => the activation tile is dead, g may overwrite it
+    // acc2[mt][nt][r] = out[row mt*16 + lr][column w*32 + nt*16 + 4g + r]
     f32x4 acc2[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc2[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -339,15 +313,24 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) tail_mma<PREC>(acc2[mt][nt], af[mt], b[nt]);
+            for (int nt = 0; nt < 2; ++nt) tail_mma<PREC>(acc2[mt][nt], b[nt], af[mt]);
     };
     load_b_B(b2f[0], 0); load_b_B(b2f[1], 1); load_b_B(b2f[2], 2);
     gelu_store(0);
     __syncthreads();
     stamp(3);
     constexpr int CPS = NKC / 4;   // k-chunks per step (4 for 16-bit: K-stages 2j, 2j+1; 8 for f32)
+    const int qlen = a.rs.len[t.seg];
+    f32x4 xres[4][2];              // residual rows, same (row, 4 columns) per lane as acc2
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+        if (j == 3) {              // issue the residual loads so that they land under the last step's MFMAs
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    xres[mt][nt] = *reinterpret_cast<const f32x4*>(a.X + (long long)(t.grow0 + mt * 16 + lr) * 256 + w * 32 + nt * 16 + 4 * g);
+        }
 #pragma unroll
         for (int i = 0; i < CPS; ++i) {
             const int kc = j * CPS + i;
@@ -360,50 +343,27 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         }
     }
     stamp(4);
-    // residual rows for the epilogue: issue the loads now so that they land during the output staging
-    const int qlen = a.rs.len[t.seg];
-    f32x4 xres[8];
+    // ------------------------------------------------------------------ epilogue: + b2, + x, store; next block's activation tile
+    // NEXT: the tile goes to K-stages 0..3 of the g planes (hi at 0, lo at G_PLANE): every wave is past the barrier that
+    // ended step 2, so nobody reads those stages any more (step 3 reads stages 6, 7) — no barrier needed here.
+    // (loads before the first store: the compiler must assume that x aliases b2, see lg_proj_body.h)
+    const f32x4 b2v[2] = {*reinterpret_cast<const f32x4*>(a.b2 + w * 32 + 4 * g), *reinterpret_cast<const f32x4*>(a.b2 + w * 32 + 16 + 4 * g)};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = tid + TTHREADS * i, row = c >> 6, c4 = c & 63;
-        xres[i] = *reinterpret_cast<const f32x4*>(a.X + (long long)(t.grow0 + row) * 256 + c4 * 4);
-    }
-    // NEXT: rotary tables of the tile for the next projection (registers now, LDS after the g tiles are dead)
-    f32x4 ropec = {0.f, 0.f, 0.f, 0.f}, ropes = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (NEXT == 1) {
-        ropec = *reinterpret_cast<const f32x4*>(a.next.cosb + (long long)t.grow0 * 32 + tid * 4);
-        ropes = *reinterpret_cast<const f32x4*>(a.next.sinb + (long long)t.grow0 * 32 + tid * 4);
-    }
-    char* smA = smem + OT_BYTES;                                   // next projection: activation tile (operand precision)
-    float* smCS = reinterpret_cast<float*>(smA + PJL<PREC>::A_BYTES);   //                  rotary tables
-    __syncthreads();   // g tiles are dead; reuse the region as a [64][256+4] fp32 output tile
-    {
-        float* ot = reinterpret_cast<float*>(smem);
-        constexpr int OLD = OT_LD;   // padded row stride (floats): rows 4g+r land on different banks
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = w * 32 + nt * 16 + 4 * g;
+        const f32x4 b2 = b2v[nt];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int col = w * 32 + nt * 16 + lr;
-            const float b2 = a.b2[col];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ot[(mt * 16 + g * 4 + r) * OLD + col] = acc2[mt][nt][r] + b2;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {     // 64 rows x 64 float4 = 4096 chunks, 8 per thread; a wave covers one full row
-            const int c = tid + TTHREADS * i, row = c >> 6, c4 = c & 63;
-            const f32x4 d = *reinterpret_cast<const f32x4*>(ot + row * OLD + c4 * 4);
-            const f32x4 xn = xres[i] + d;
-            if (t.r0 + row < qlen) *reinterpret_cast<f32x4*>(a.X + (long long)(t.grow0 + row) * 256 + c4 * 4) = xn;
-            if constexpr (NEXT != 0) {   // the same 4 columns, in operand precision, into the projection's A tile
+        for (int mt = 0; mt < 4; ++mt) {
+            const int row = mt * 16 + lr;
+            const f32x4 xn = xres[mt][nt] + (acc2[mt][nt] + b2);
+            if (t.r0 + row < qlen) *reinterpret_cast<f32x4*>(a.X + (long long)(t.grow0 + row) * 256 + col) = xn;
+            if constexpr (NEXT != 0) {
                 static_assert(EPC == 8, "fused next projection: 16-bit operands only");
-                const int col = c4 * 4;
-                char* dst = smA + (col >> 6) * PJL<PREC>::TILE + lds_off<128>(row, (col & 63) >> 3) + (col & 7) * 2;
+                char* dst = smem + (col >> 6) * TILE + lds_off<128>(row, (col & 63) >> 3) + (col & 7) * 2;
                 if constexpr (PREC == PREC_BF16X3) {
                     const float h0 = bf16_round(xn[0]), h1 = bf16_round(xn[1]), h2 = bf16_round(xn[2]), h3 = bf16_round(xn[3]);
                     *reinterpret_cast<u32x2*>(dst) = u32x2{pack2_bf16(h0, h1), pack2_bf16(h2, h3)};
-                    *reinterpret_cast<u32x2*>(dst + PJL<PREC>::A_PLANE) = u32x2{pack2_bf16(xn[0] - h0, xn[1] - h1), pack2_bf16(xn[2] - h2, xn[3] - h3)};
+                    *reinterpret_cast<u32x2*>(dst + G_PLANE) = u32x2{pack2_bf16(xn[0] - h0, xn[1] - h1), pack2_bf16(xn[2] - h2, xn[3] - h3)};
                 } else {
                     *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<Tag>(xn[0], xn[1]), pack2<Tag>(xn[2], xn[3])};
                 }
@@ -411,23 +371,13 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         }
     }
     stamp(5);
-    if constexpr (NEXT != 0) {
-        if constexpr (NEXT == 1) {
-            *reinterpret_cast<f32x4*>(smCS + tid * 4) = ropec;
-            *reinterpret_cast<f32x4*>(smCS + 2048 + tid * 4) = ropes;
-        }
-        // staging of the projection outputs aliases the fp32 output tile: every thread is past its reads of it when it
-        // reaches the barrier inside proj_compute, and the staging is first written after that barrier
-        proj_compute<PREC, TA, NEXT == 1 ? 3 : 2, 2>(a.next, t, smA, smem, smCS, 8);
-    }
+    if constexpr (NEXT != 0) proj_compute<PREC, TA, NEXT == 1 ? 3 : 2, 2, G_PLANE>(a.next, t, smem, 8);
 }
 
 template <int PREC, int NEXT, class TA> static hipError_t launch_tail_t(const TailArgs& a, hipStream_t s) {
     const int R = a.rs.B * (a.rs.cap0 + a.rs.cap1);
     auto kern = tail_kernel<PREC, NEXT, TA>;
-    constexpr int base = TL<PREC>::TOTAL > OT_BYTES ? TL<PREC>::TOTAL : OT_BYTES;
-    constexpr int fused = OT_BYTES + PJL<PREC>::A_BYTES + PJ_CS_BYTES;
-    constexpr int smem = (NEXT != 0 && fused > base) ? fused : base;
+    constexpr int smem = TL<PREC>::TOTAL;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(R / TBM), dim3(TTHREADS), smem, s, a);
@@ -435,7 +385,6 @@ template <int PREC, int NEXT, class TA> static hipError_t launch_tail_t(const Ta
 }
 template <int PREC, class TA> static hipError_t launch_tail_next(const TailArgs& a, hipStream_t s) {
     if (!a.next.W) return launch_tail_t<PREC, 0, TA>(a, s);
-    static_assert(PJO<TA, 3>::O_BYTES <= OT_BYTES, "projection staging must fit the dead output tile");
     if (a.next.Nout == 768 && a.next.cosb) return launch_tail_t<PREC, 1, TA>(a, s);
     if (a.next.Nout == 512 && !a.next.cosb) return launch_tail_t<PREC, 2, TA>(a, s);
     return hipErrorInvalidValue;

@@ -38,6 +38,8 @@ def oracle_conf_for(case):
     from oracle import lightglue_oracle as O
     kw = dict(case["conf"])
     kw["pruning_min_kpts"] = case.get("prune_th", -1)  # reference ran on CPU: class dict 'cpu' = -1 unless overridden
+    if case.get("static_lengths") and max(case["n"], case["m"]) <= max(case["static_lengths"]):
+        kw["width_confidence"] = -1                    # ref :529: no point pruning inside the static-length range
     return O.make_conf(**kw)
 
 

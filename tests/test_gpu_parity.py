@@ -24,6 +24,8 @@ def run_case(name, precision):
     if "prune_th" in case:
         kw["pruning_min_kpts"] = case["prune_th"]
     model = gpu_util.make_model(sd, precision, **kw)
+    if case.get("static_lengths"):
+        model.static_lengths = list(case["static_lengths"])   # what compile() sets (ref :454)
     out = model(gpu_util.to_torch(data))
     torch.cuda.synchronize()
     return case, sd, data, gold, out
@@ -49,6 +51,8 @@ def test_fp32_mode_matches_golden_exactly(name):
         assert ml.dtype == np.int64 and (np.diff(ml[:, 0]) > 0).all()          # sorted by index0 (ref :596)
         np.testing.assert_array_equal(ml[:, 1], gold["matches0"][b][ml[:, 0]])
     pruning = case["conf"].get("width_confidence", 0.99) > 0
+    if case.get("static_lengths") and max(case["n"], case["m"]) <= max(case["static_lengths"]):
+        pruning = False                                                        # ref :529
     assert out["prune0"].dtype == (torch.int64 if pruning else torch.float32)  # ref :535 vs :616
 
 

@@ -6,7 +6,7 @@ __init__ needs torchvision/kornia/cv2 which are absent) on CPU in
 inputs are regenerated from seeds by oracle/synth.py (numpy only), so a fixture stores just the case
 description, a digest of the weights, and the reference outputs.
 
-    python tools/make_golden.py            # rewrites every fixture
+    python tools/make_golden.py [name ...]  # rewrites every fixture (or the named ones)
 The fixtures are committed; the GPU box never needs /root/reference.
 """
 from __future__ import annotations
@@ -40,6 +40,20 @@ CASES = {
     "stop_only_600": dict(recipe="B", wseed=0, dseed=91, B=1, n=600, m=600, dim=256, prune_th=-1, conf=dict(width_confidence=-1)),
     "prune_only_600": dict(recipe="B", wseed=0, dseed=101, B=1, n=600, m=600, dim=256, prune_th=-1, conf=dict(depth_confidence=-1)),
     "empty_0x50": dict(recipe="A", wseed=0, dseed=111, B=1, n=0, m=50, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1)),
+    # ---- BASELINE.json configs at their own shapes (round 2; VERDICT r01 "next" item 1)
+    # cfg #2: the first 4 pairs of bench.py's own batch (weights seed 0 recipe A, pair seeds 1..4)
+    "nonadaptive_1024_b4": dict(recipe="A", wseed=0, dseed=1, B=4, n=1024, m=1024, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1)),
+    # cfg #3: N=M=2048 adaptive, with the reference's flash threshold (ref :339-344) and with pruning from layer 0
+    "adaptive_2048_th1536": dict(recipe="B", wseed=0, dseed=201, B=1, n=2048, m=2048, dim=256, prune_th=1536, conf=dict()),
+    "adaptive_2048_thm1": dict(recipe="B", wseed=0, dseed=202, B=1, n=2048, m=2048, dim=256, prune_th=-1, conf=dict()),
+    # cfg #4: DISK 128-d, N=M=4096
+    "disk128_4096": dict(recipe="A", wseed=3, dseed=301, B=1, n=4096, m=4096, dim=128, conf=dict(depth_confidence=-1, width_confidence=-1, input_dim=128)),
+    # cfg #5: ALIKED 128-d, 2048 x 512, pruning on with the 1536 threshold (only image0 can be pruned, ref :551/:559)
+    "aliked128_2048x512_prune1536": dict(recipe="B", wseed=2, dseed=401, B=2, n=2048, m=512, dim=128, prune_th=1536, conf=dict(input_dim=128)),
+    # a18: the compiled path's semantics without torch.compile (ref :512-520, :529): inputs inside the static range are
+    # padded with ones and masked, pruning off, early stop on; above the range nothing changes
+    "static_lengths_256_512_in_range": dict(recipe="B", wseed=0, dseed=501, B=1, n=300, m=420, dim=256, prune_th=-1, static_lengths=[256, 512], conf=dict()),
+    "static_lengths_256_512_above_range": dict(recipe="B", wseed=0, dseed=502, B=1, n=600, m=500, dim=256, prune_th=256, static_lengths=[256, 512], conf=dict()),
 }
 
 
@@ -79,6 +93,8 @@ def run_reference(lg, case: dict):
             lg.LightGlue.pruning_keypoint_thresholds[k] = case["prune_th"]
     try:
         model = lg.LightGlue(features=None, **case["conf"]).eval()
+        if case.get("static_lengths"):
+            model.static_lengths = list(case["static_lengths"])   # what compile() sets (ref :454), without torch.compile
         res = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
         assert not res.unexpected_keys and set(res.missing_keys) <= {"confidence_thresholds"}, res
         outs = []
@@ -104,7 +120,10 @@ def main():
     lg = load_reference()
     out_dir = ROOT / "tests" / "golden"
     out_dir.mkdir(parents=True, exist_ok=True)
+    only = set(sys.argv[1:])
     for name, case in CASES.items():
+        if only and name not in only:
+            continue
         sd, out = run_reference(lg, case)
         meta = dict(case=case, weights_sha256=synth.state_dict_digest(sd), torch=torch.__version__, numpy=np.__version__,
                     reference="cvg/LightGlue lightglue/lightglue.py (CPU fp32, loaded standalone)")

@@ -13,10 +13,10 @@ sd = synth.make_state_dict(0, recipe="A")
 model = gpu_util.make_model(sd, prec, depth_confidence=-1, width_confidence=-1)
 data = gpu_util.to_torch(synth.make_batch(1, 32, 1024, 1024))
 model(data); model.set_option("tail_timing", which); model(data); torch.cuda.synchronize()
-nst = 6 if which == 1 else 8
+nst = 6
 d = model.debug_read("TAILDBG", np.int64).reshape(-1, 8, 8)[:, :, :nst]
 dt = np.diff(d, axis=2).astype(np.float64)
-names = ["phaseA", "LN", "GELU0", "phaseB+GELU", "epilogue"] if which == 1 else ["A tile -> LDS", "pass0 MFMA", "pass0 bias/rope/stage", "pass0 store", "pass1 MFMA", "pass1 stage", "pass1 store"]
+names = ["phaseA", "LN", "GELU0", "phaseB+GELU", "epilogue"] if which == 1 else ["A tile -> LDS", "pass0 MFMA", "pass0 epilogue", "pass1 MFMA", "pass1 epilogue"]
 print(prec, "clock ticks per wave (median / p10 / p90) over", dt.shape[0], "blocks x 8 waves; s_memtime ticks at 100 MHz => x ~21 shader cycles")
 for i, n in enumerate(names):
     v = dt[:, :, i].ravel()

@@ -172,6 +172,15 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     constexpr int NBUF = NPART == 2 ? 2 : 4;
     u32x4 bf[NBUF][4][NPART];   // ring of B fragments: this wave's 4 n-tiles x planes per k-chunk
     auto load_b_A = [&](u32x4 (&dst)[4][NPART], int kc) {
+#ifdef LG_AB_NOWLOAD   // ablation: no weight stream in phase A (fragments stay whatever the first loads brought)
+        if (kc >= NBUF) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int p = 0; p < NPART; ++p) asm volatile("" : "+v"(dst[nt][p]));
+            return;
+        }
+#endif
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -183,12 +192,29 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int p = 0; p < NPART; ++p)
+            for (int p = 0; p < NPART; ++p) {
+#ifdef LG_AB_NOLDS     // ablation: no activation-fragment reads in phase A
+                af[mt][p] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; asm volatile("" : "+v"(af[mt][p]));
+#else
                 af[mt][p] = *reinterpret_cast<const u32x4*>(tile + p * G_PLANE + lds_off<128>(mt * 16 + lr, (kc & 1) * 4 + g));
+#endif
+            }
+#ifdef LG_PRODUCT_MAJOR
+        if constexpr (NPART == 2) {   // product-major: 16 independent MFMAs per product, no back-to-back dependent pairs
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) mma_chunk<Tag>(acc[mt][nt], b[nt][pr == 1 ? 1 : 0], af[mt][pr == 0 ? 1 : 0]);
+        } else
+#endif
+        {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) tail_mma<PREC>(acc[mt][nt], b[nt], af[mt]);
+        }
     };
     load_half(0);
 #pragma unroll

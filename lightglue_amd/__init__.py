@@ -7,8 +7,8 @@ Feature extractors, image I/O and visualisation are out of scope
 """
 from .lightglue import LightGlue  # noqa: F401
 from .parallel import PairShardedMatcher, shard_range  # noqa: F401
-from .glue import batch_to_device, collate_features, match_batch, match_pair, rbd  # noqa: F401
+from .glue import batch_to_device, collate_features, extracted_to_image_frame, match_batch, match_pair, rbd  # noqa: F401
 
-__all__ = ["LightGlue", "PairShardedMatcher", "shard_range", "match_pair", "match_batch", "collate_features", "rbd",
+__all__ = ["LightGlue", "PairShardedMatcher", "shard_range", "match_pair", "match_batch", "collate_features", "extracted_to_image_frame", "rbd",
            "batch_to_device"]
 __version__ = "0.2.0"

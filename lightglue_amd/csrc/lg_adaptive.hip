@@ -22,7 +22,12 @@ __global__ __launch_bounds__(256) void adapt_decide_kernel(AdaptArgs a) {
     __shared__ int sh_cnt[4];
     __shared__ int sh_stop;
     __shared__ int sh_newlen[2];
-    if (!a.active[pair]) return;
+    if (!a.active[pair]) {
+        // a pair that stopped (or lost all points of an image) at an earlier layer: make sure adapt_compact skips it —
+        // len_old of the layer that pruned it must not be replayed at every later layer
+        if (tid < 2) a.len_old[2 * pair + tid] = -1;
+        return;
+    }
     const int len0 = a.len[2 * pair], len1 = a.len[2 * pair + 1];
 
     if (a.do_stop) {

@@ -331,6 +331,7 @@ int lg_engine_create(const lg_config* cfg, lg_engine** out) {
 
 void lg_engine_destroy(lg_engine* e) {
     if (!e) return;
+    for (auto& sp : e->prof_pool) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     if (e->ws) (void)hipFree(e->ws);
     if (e->w_arena) (void)hipFree(e->w_arena);
     delete e;
@@ -808,6 +809,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
         as.matches = io->matches; as.mscores = io->match_scores; as.n_matches = io->n_matches; as.max_matches = max_matches;
         as.log_assignment = io->log_assignment; as.lsneg = e->MSCORE;
         as.dbg = e->tail_timing == 4 ? e->TAILDBG : nullptr;
+        as.all_rows_live = (!do_prune && !io->num0 && !io->num1) ? 1 : 0;
         TRY(prof_begin(e, PC_ASSIGN, s));
         HIPCHK(launch_assign(as, s));
         TRY(prof_end(e, s));

@@ -155,6 +155,7 @@ struct AssignArgs {
     // optional full log-assignment [B][n0+1][n1+1] (ref :265-277) + logsigmoid(-z) per row for its dustbins
     float* log_assignment; const float* lsneg;
     long long* dbg;   // profiling tap (tail_timing == 4): per sweep workgroup [3] shader-clock stamps
+    int all_rows_live; // 1: len == n for every segment (no pruning ever, no ragged counts): the -1 / 0 pre-fill of m/s is skipped
 };
 hipError_t launch_assign(const AssignArgs& a, hipStream_t s);
 

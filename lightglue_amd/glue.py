@@ -43,6 +43,21 @@ def match_pair(extractor, matcher, image0: torch.Tensor, image1: torch.Tensor, d
     return feats0, feats1, matches01
 
 
+def extracted_to_image_frame(feats: Dict[str, Any], original_hw, scales: torch.Tensor) -> Dict[str, Any]:
+    """The last two steps of the reference's `Extractor.extract` (`lightglue/utils.py:142-147`) for an extractor that
+    ran on a RESIZED image: keypoints go back to the original image's pixel frame, `(k + 0.5) / scales - 0.5`, and
+    `image_size` = original (width, height) is attached — the two fields the matcher's keypoint normalisation reads
+    (`lightglue.py:32-43`).  `original_hw` = (H, W) of the image before resizing, `scales` = resized / original per axis
+    (x, y) as the reference's ImagePreprocessor returns it."""
+    kp = feats["keypoints"]
+    scales = torch.as_tensor(scales, dtype=kp.dtype, device=kp.device)
+    out = dict(feats)
+    out["keypoints"] = (kp + 0.5) / scales[None] - 0.5
+    h, w = int(original_hw[0]), int(original_hw[1])
+    out["image_size"] = torch.tensor([[w, h]], dtype=kp.dtype, device=kp.device)
+    return out
+
+
 _PER_KEYPOINT = ("keypoints", "descriptors", "scales", "oris", "keypoint_scores")
 
 

@@ -253,7 +253,7 @@ class LightGlue(nn.Module):
             ver += p._version
         sig = (ver, plist[0].data_ptr(), plist[-1].data_ptr(), len(plist))
         if sig == self._weights_sig:
-            return
+            return   # (edits through `.data` bypass the version counter: call refresh_weights() after those)
         lib = _cabi.load()
         keep = []
         for name, p in self.state_dict().items():
@@ -266,6 +266,27 @@ class LightGlue(nn.Module):
         with torch.cuda.device(device):
             _cabi.check(lib.lg_engine_finalize_weights(handle))
         self._weights_sig = sig
+
+    def refresh_weights(self):
+        """Force a re-pack + upload of the parameters at the next forward (needed after edits the version counters do
+        not see, e.g. ``p.data.copy_()`` or module surgery)."""
+        self._weights_sig = None
+        self._plist = None
+
+    def _apply(self, fn, *a, **kw):                      # .to() / .cuda() / .half() ...
+        out = super()._apply(fn, *a, **kw)
+        self.refresh_weights()
+        return out
+
+    def load_state_dict(self, *a, **kw):                 # incl. assign=True, which replaces the Parameter objects
+        out = super().load_state_dict(*a, **kw)
+        self.refresh_weights()
+        return out
+
+    def __getstate__(self):                              # copy.deepcopy / pickle / torch.save(model): the engine handle
+        st = dict(self.__dict__)                         # is process-local; the copy creates its own lazily
+        st["_engine"] = None; st["_plist"] = None; st["_weights_sig"] = None
+        return st
 
     def reserve(self, batch: int, n0: int, n1: int, device=None):
         """Pre-size the engine workspace (avoids a synchronising re-allocation inside forward)."""
@@ -315,8 +336,9 @@ class LightGlue(nn.Module):
                 return None
             if not isinstance(s, torch.Tensor):
                 s = torch.tensor(s, dtype=torch.float32)
-            s = f32(s)
-            return s.expand(b, 2).contiguous() if s.dim() == 1 else s
+            s = f32(s).reshape(-1, 2)
+            assert s.shape[0] in (1, b), f"image_size must have shape [2], [1, 2] or [{b}, 2]"
+            return s if s.shape[0] == b else s.expand(b, 2).contiguous()   # the reference broadcasts (ref :35-42)
 
         size0, size1 = as_size(size0), as_size(size1)
         extra = [None] * 4
@@ -395,7 +417,7 @@ class LightGlue(nn.Module):
         counts = host[1]
         matches = [row[:c] for row, c in zip(mlist64.unbind(0), counts)]
         mscores = [row[:c] for row, c in zip(mscore_list.unbind(0), counts)]
-        if not do_early_stop and m > 0 and n > 0 and not ragged:
+        if not do_early_stop and not do_point_pruning and m > 0 and n > 0 and not ragged:
             stop_out = conf.n_layers if b == 1 else torch.full((b,), conf.n_layers, device=device, dtype=torch.long)
         else:
             stop_out = int(host[0][0]) if b == 1 else stop64

@@ -9,7 +9,7 @@ import torch
 
 import gpu_util
 import make_golden
-from conftest import SCORE_TOL, explain_mismatches, golden_names, load_golden, oracle_conf_for, require_gpu
+from conftest import SCORE_TOL, assert_parity_with_explained_flips, explain_mismatches, golden_names, load_golden, oracle_conf_for, require_gpu
 from lightglue_amd import synthetic as synth
 from oracle import lightglue_oracle as O
 
@@ -58,26 +58,118 @@ def test_fp32_mode_matches_golden_exactly(name):
 
 @pytest.mark.parametrize("name", golden_names())
 def test_default_precision_parity(name):
+    """bf16x3 against the reference's fixtures on BOTH image sides: scores within 1e-3, every index flip traced to an
+    oracle-side decision boundary within 2 x tolerance in score space; stop layers and both prune counters identical."""
     require_gpu()
     case, sd, data, gold, out = run_case(name, "bf16x3")
-    m0, s0 = out["matches0"].cpu().numpy(), out["matching_scores0"].cpu().numpy()
-    assert np.abs(s0 - gold["matching_scores0"]).max(initial=0.0) <= SCORE_TOL
-    assert np.abs(out["matching_scores1"].cpu().numpy() - gold["matching_scores1"]).max(initial=0.0) <= SCORE_TOL
     adaptive = case["conf"].get("depth_confidence", 0.95) > 0 or case["conf"].get("width_confidence", 0.99) > 0
-    if (m0 != gold["matches0"]).any():
-        assert not adaptive, "index mismatch on an adaptive case"
-        conf = oracle_conf_for(case)
-        for b in range(m0.shape[0]):
-            tr = {}
-            g = lambda d, k: None if d.get(k) is None else np.asarray(d[k])[b]
-            d0, d1 = data["image0"], data["image1"]
-            ref = O.forward_pair(sd, conf, g(d0, "keypoints"), g(d1, "keypoints"), g(d0, "descriptors"), g(d1, "descriptors"),
-                                 g(d0, "image_size"), g(d1, "image_size"), g(d0, "scales"), g(d0, "oris"), g(d1, "scales"), g(d1, "oris"), trace=tr)
-            un = explain_mismatches(m0[b], s0[b], ref, filter_threshold=conf.filter_threshold, scores_full=tr["scores_full"], ind0=tr["ind0"], ind1=tr["ind1"])
-            assert un == 0, f"{un} unexplained index mismatches in pair {b}"
+    flips = assert_parity_with_explained_flips(out, gold, case, sd, data)
+    if adaptive:
+        assert flips == (0, 0), f"index mismatch on an adaptive case: {flips}"
     stop = out["stop"] if not torch.is_tensor(out["stop"]) else out["stop"].cpu().tolist()
     assert np.atleast_1d(stop).tolist() == gold["stop"].tolist()
     np.testing.assert_array_equal(out["prune0"].cpu().numpy().astype(np.float32), gold["prune0"])
+    np.testing.assert_array_equal(out["prune1"].cpu().numpy().astype(np.float32), gold["prune1"])
+
+
+def test_fp16_mode_envelope_on_the_pruning_config():
+    """BASELINE cfg #5 names fp16.  precision='fp16' (single f16 MFMA per product) does NOT hold the 1e-3 bar — the measured
+    envelope on the cfg #5 fixture is asserted here so that it is documented, not hidden: scores within 3e-2, at most 1 % index
+    flips, stop layers identical.  (The parity-holding mode for this config is bf16x3, covered above.)"""
+    require_gpu()
+    case, sd, data, gold, out = run_case("aliked128_2048x512_prune1536", "fp16")
+    m0 = out["matches0"].cpu().numpy()
+    assert (m0 != gold["matches0"]).mean() <= 0.01
+    both = (m0 == gold["matches0"])
+    assert np.abs(out["matching_scores0"].cpu().numpy() - gold["matching_scores0"])[both].max(initial=0.0) <= 3e-2
+    stop = out["stop"] if not torch.is_tensor(out["stop"]) else out["stop"].cpu().tolist()
+    assert np.atleast_1d(stop).tolist() == gold["stop"].tolist()
+
+
+def test_all_points_pruned_ends_the_pair_like_the_reference():
+    """An image whose points are ALL pruned at layer i: the reference leaves its loop at the next iteration's empty guard
+    (ref :539-540) -> stop = i + 2, empty matches, prune counters untouched after that layer.  Later layers must not
+    replay the compaction of the layer that emptied the image."""
+    require_gpu()
+    sd = synth.make_state_dict(0, recipe="B")
+    sd = {k: v.copy() for k, v in sd.items()}
+    for i in range(9):
+        sd[f"log_assignment.{i}.matchability.bias"] -= np.float32(200.0)
+    kw = dict(depth_confidence=-1, pruning_min_kpts=-1)
+    for B in (1, 3):
+        data = synth.make_batch(5, B, 300, 260)
+        ref = O.forward(sd, O.make_conf(**kw), data)
+        assert ref["stop"] == [2] * B and all(len(m) == 0 for m in ref["matches"])
+        model = gpu_util.make_model(sd, "fp32", **kw)
+        out = model(gpu_util.to_torch(data))
+        stop = [int(out["stop"])] if B == 1 else out["stop"].cpu().tolist()
+        assert stop == ref["stop"]
+        np.testing.assert_array_equal(out["prune0"].cpu().numpy(), ref["prune0"])
+        np.testing.assert_array_equal(out["prune1"].cpu().numpy(), ref["prune1"])
+        assert (out["matches0"] == -1).all() and (out["matches1"] == -1).all() and all(x.shape[0] == 0 for x in out["matches"])
+
+
+def test_image_size_is_broadcast_over_the_batch():
+    """ref :35-42 broadcasts a [1, 2] (or [2]) image_size over B; the engine reads B rows."""
+    require_gpu()
+    sd = synth.make_state_dict(0, recipe="A")
+    model = gpu_util.make_model(sd, "fp32", depth_confidence=-1, width_confidence=-1)
+    t = gpu_util.to_torch(synth.make_batch(31, 3, 200, 180))
+    full = model(t)
+    for shape in ((1, 2), (2,)):
+        t2 = {k: dict(v) for k, v in t.items()}
+        for k in t2:
+            t2[k]["image_size"] = t[k]["image_size"][0].reshape(shape)
+        out = model(t2)
+        assert torch.equal(out["matches0"], full["matches0"]) and torch.equal(out["matching_scores0"], full["matching_scores0"])
+
+
+def test_nan_descriptors_do_not_fault_and_do_not_leak_into_other_pairs():
+    """NaN in one pair's descriptors: the reference returns garbage for that pair but does not crash; here the argmax
+    sentinel of an all-NaN row must not be used as an index, and the other pairs must be untouched."""
+    require_gpu()
+    sd = synth.make_state_dict(0, recipe="A")
+    model = gpu_util.make_model(sd, "bf16x3", depth_confidence=-1, width_confidence=-1)
+    t = gpu_util.to_torch(synth.make_batch(41, 3, 300, 280))
+    clean = model(t)
+    t["image0"]["descriptors"][1] = float("nan")
+    out = model(t)
+    torch.cuda.synchronize()
+    for b in (0, 2):
+        assert torch.equal(out["matches0"][b], clean["matches0"][b]) and torch.equal(out["matching_scores0"][b], clean["matching_scores0"][b])
+    assert int(out["matches"][1].shape[0]) == 0 and (out["matches0"][1] == -1).all()
+
+
+def test_legacy_named_checkpoint_from_the_weights_directory():
+    """SURVEY §8 f1 end to end on the GPU: a released-style .pth (self_attn.{i}.* / cross_attn.{i}.* keys, ref :427-434) in the
+    package's weights/ directory, loaded through LightGlue(features=None, weights=...) (ref :422-425), must reproduce the golden."""
+    require_gpu()
+    import os
+    from pathlib import Path
+    import lightglue_amd
+    meta, gold = load_golden("nonadaptive_512")
+    sd, data = make_golden.case_inputs(meta["case"])
+    legacy = {}
+    for k, v in sd.items():
+        for i in range(9):
+            k = k.replace(f"transformers.{i}.self_attn", f"self_attn.{i}").replace(f"transformers.{i}.cross_attn", f"cross_attn.{i}")
+        legacy[k] = torch.from_numpy(v)
+    assert any(k.startswith("cross_attn.8.") for k in legacy)
+    wdir = Path(lightglue_amd.__file__).parent / "weights"
+    wdir.mkdir(exist_ok=True)
+    name = f"_test_legacy_{os.getpid()}"
+    path = wdir / f"{name}.pth"
+    torch.save(legacy, str(path))
+    try:
+        model = lightglue_amd.LightGlue(features=None, weights=name, precision="fp32", **meta["case"]["conf"]).eval()
+    finally:
+        path.unlink()
+        if not any(wdir.iterdir()):
+            wdir.rmdir()
+    out = model(gpu_util.to_torch(data))
+    np.testing.assert_array_equal(out["matches0"].cpu().numpy(), gold["matches0"])
+    np.testing.assert_array_equal(out["matches1"].cpu().numpy(), gold["matches1"])
+    np.testing.assert_allclose(out["matching_scores0"].cpu().numpy(), gold["matching_scores0"], atol=2e-4, rtol=0)
 
 
 @pytest.mark.parametrize("fused", [False, True])

@@ -137,3 +137,41 @@ def test_collate_features_pads_and_counts():
     assert batch["image_size"].shape == (3, 2)
     assert torch.equal(batch["keypoints"][0, :5], feats[0]["keypoints"]) and (batch["keypoints"][0, 5:] == 0).all()
     assert torch.equal(batch["descriptors"][1], feats[1]["descriptors"][0])
+
+
+def test_extracted_to_image_frame_matches_reference_formula():
+    """ref utils.py:142-147: keypoints back to the original frame + image_size (w, h)."""
+    from lightglue_amd import extracted_to_image_frame
+    kp = torch.tensor([[[0.0, 0.0], [99.5, 49.5], [10.0, 20.0]]])
+    feats = {"keypoints": kp, "descriptors": torch.zeros(1, 3, 256)}
+    out = extracted_to_image_frame(feats, (480, 640), torch.tensor([0.5, 0.25]))
+    assert torch.allclose(out["keypoints"], (kp + 0.5) / torch.tensor([0.5, 0.25])[None] - 0.5)
+    assert out["image_size"].tolist() == [[640.0, 480.0]] and out["descriptors"] is feats["descriptors"]
+    assert torch.equal(feats["keypoints"], kp)   # input not mutated
+
+
+def test_model_can_be_deep_copied_and_pickled():
+    """The reference module can be copied / pickled; the process-local engine handle must not get in the way."""
+    import copy, pickle
+    m = LightGlue(features=None, n_layers=2)
+    m._engine = ("not-a-real-handle", None)     # what a forward would have left behind
+    m._plist = list(m.parameters()); m._weights_sig = (1, 2, 3, 4)
+    c = copy.deepcopy(m)
+    assert c._engine is None and c._plist is None and c._weights_sig is None
+    assert torch.equal(c.state_dict()["transformers.1.self_attn.Wqkv.weight"], m.state_dict()["transformers.1.self_attn.Wqkv.weight"])
+    r = pickle.loads(pickle.dumps(m))
+    assert r._engine is None and r.conf.n_layers == 2
+    m.__dict__["_engine"] = None                # do not hand the fake handle to lg_engine_destroy
+
+
+def test_weight_changes_invalidate_the_packed_copy():
+    m = LightGlue(features=None, n_layers=2)
+    m._plist = list(m.parameters()); m._weights_sig = (0, 0, 0, 0)
+    m.load_state_dict(m.state_dict())
+    assert m._weights_sig is None and m._plist is None
+    m._weights_sig = (0, 0, 0, 0)
+    m.float()                                   # any _apply (.to / .cuda / .half)
+    assert m._weights_sig is None
+    m._weights_sig = (0, 0, 0, 0)
+    m.refresh_weights()
+    assert m._weights_sig is None

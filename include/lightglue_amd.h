@@ -111,9 +111,10 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream);
  *   "fused_proj"   1  full-width q/k/v projection kernel (lg_proj.hip); 0 = generic GEMM with the QKV epilogue
  *   "fused_next"   1  the tail kernel also runs the NEXT block's q/k/v projection on the x tile it has just produced
  *                     (bit-identical to the separate kernel; needs fused_tail, fused_proj and 16-bit operand precisions)
- *   "tail_variant" 0  0 = lg_tail.hip; lg_tail4.hip decompositions: 1 = 4 waves x 64 rows, 2 = 8 waves x 128 rows,
- *                     3 = 4 waves x 32 rows (all correct, none faster; env LG_TAIL_VARIANT)
- *   "attn_rows"    32 query rows per attention wave: 16 | 32 | 64 (bit-identical outputs; env LG_ATTN_ROWS)
+ *   "tail_variant" 0  product library: only 0 (lg_tail.hip) is accepted.  Experiment builds (make EXPERIMENTS=1 / -DLG_EXPERIMENTS) add
+ *                     the lg_tail4.hip decompositions 1 = 4 waves x 64 rows, 2 = 8 waves x 128 rows, 3 = 4 waves x 32 rows (all
+ *                     correct, none faster) and the LG_TAIL_VARIANT / LG_ATTN_ROWS environment switches; the product reads no environment
+ *   "attn_rows"    32 query rows per attention wave: 16 | 32 | 64 (bit-identical outputs)
  *   "profile_only" -1 restrict the HIP-event timing of lg_engine_profile_enable to one kernel class (index of
  *                     lg_profile_class_name), -1 = all classes
  *   "tail_timing"  0  shader-clock taps: 1 tail kernel, 2 self projection, 3 attention (LG_ATTN_TIMING builds) */

@@ -95,9 +95,8 @@ struct lg_engine {
     char *w_sqkv_p = nullptr, *w_cqkv_p = nullptr;   // fragment-packed projection weights (lg_proj.hip)
     size_t sqkv_layer_bytes = 0, cqkv_layer_bytes = 0;
     int attn_rows = 32;   // query rows per attention wave (32 | 64), option "attn_rows" / env LG_ATTN_ROWS
-    int fused_tail = 1, fused_proj = 1, fused_next = 1, tail_variant = 0;   // 0 = lg_tail.hip (64 rows, LDS-resident), 1 = 4 waves x 64 rows, 2 = 8 waves x 128 rows
+    int fused_tail = 1, fused_proj = 1, fused_next = 1, tail_variant = 0;   // tail_variant != 0: experiment builds only (lg_tail4.hip)
     int tail_timing = 0; long long* TAILDBG = nullptr;
-    int tail_stagger = 0; int* STAG = nullptr;
     // ---- workspace
     void* ws = nullptr; size_t ws_bytes = 0;
     int capB = 0, cap0 = 0, cap1 = 0;      // reserved
@@ -221,7 +220,6 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
         add(R * 4); add(R * 4);                                 // IND DST
         for (int i = 0; i < 5; ++i) add((size_t)nB * 2 * 4);    // LEN LEN_ORIG LEN_OLD ACTIVE FINAL_LAYER
         add(R / 64 * 64 * 8);                                   // TAILDBG
-        add(2048 * 4);                                          // STAG
         total += 4096;
         HIPCHK(hipMalloc(&e->ws, total));
         e->ws_bytes = total;
@@ -251,7 +249,6 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
     e->LEN = (int*)take("LEN", (size_t)B * 2 * 4); e->LEN_ORIG = (int*)take("LEN_ORIG", (size_t)B * 2 * 4); e->LEN_OLD = (int*)take("LEN_OLD", (size_t)B * 2 * 4);
     e->ACTIVE = (int*)take("ACTIVE", (size_t)B * 4); e->FINAL_LAYER = (int*)take("FINAL_LAYER", (size_t)B * 4);
     e->TAILDBG = (long long*)take("TAILDBG", R / 64 * 64 * 8);
-    e->STAG = (int*)take("STAG", 2048 * 4);
     if (ar.used > e->ws_bytes) return fail(LG_ERR_STATE, "workspace carve overflow");
     return LG_OK;
 }
@@ -322,9 +319,10 @@ int lg_engine_create(const lg_config* cfg, lg_engine** out) {
     if (ap < 0) ap = cfg->precision == LG_PREC_BF16X3 ? PREC_F16 : cfg->precision;
     if (ap != PREC_F32 && ap != PREC_BF16 && ap != PREC_F16) { delete e; return fail(LG_ERR_INVALID, "bad attn_precision"); }
     e->attn_prec = ap;
+#ifdef LG_EXPERIMENTS   // A/B switches of experiment builds (tools/build_variant.sh ... -DLG_EXPERIMENTS); the product reads no environment
     if (const char* tv = std::getenv("LG_TAIL_VARIANT")) e->tail_variant = std::atoi(tv);
-    if (const char* tv = std::getenv("LG_TAIL_STAGGER")) e->tail_stagger = std::atoi(tv);
-    if (const char* ar = std::getenv("LG_ATTN_ROWS")) { const int v = std::atoi(ar); e->attn_rows = (v == 64 || v == 16) ? v : 32; }   // A/B switch for experiments
+    if (const char* ar = std::getenv("LG_ATTN_ROWS")) { const int v = std::atoi(ar); e->attn_rows = (v == 64 || v == 16) ? v : 32; }
+#endif
     *out = e;
     return LG_OK;
 }
@@ -507,7 +505,11 @@ int lg_engine_reserve(lg_engine* e, int32_t max_batch, int32_t max_n0, int32_t m
 int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
     if (!e || !key) return fail(LG_ERR_INVALID, "null argument");
     if (std::strcmp(key, "fused_tail") == 0) { e->fused_tail = value != 0; return LG_OK; }
+#ifdef LG_EXPERIMENTS
     if (std::strcmp(key, "tail_variant") == 0) { e->tail_variant = value; return LG_OK; }
+#else
+    if (std::strcmp(key, "tail_variant") == 0) return value == 0 ? LG_OK : fail(LG_ERR_INVALID, "tail_variant: the streaming tail variants are experiment builds only (-DLG_EXPERIMENTS)");
+#endif
     if (std::strcmp(key, "fused_proj") == 0) { e->fused_proj = value != 0; return LG_OK; }
     if (std::strcmp(key, "fused_next") == 0) { e->fused_next = value != 0; return LG_OK; }
     if (std::strcmp(key, "attn_rows") == 0) { if (value != 16 && value != 32 && value != 64) return fail(LG_ERR_INVALID, "attn_rows must be 16, 32 or 64"); e->attn_rows = value; return LG_OK; }
@@ -713,10 +715,12 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                     ta.next = blk == 0 ? make_proj(i, 1) : make_proj(i + 1, 0);
                     proj_done = true;
                 }
-                ta.stag = e->STAG; ta.stag_delay = e->tail_variant == 1 ? e->tail_stagger : 0;
                 TRY(prof_begin(e, PC_TAIL, s));
-                if (ta.stag_delay > 0) HIPCHK(hipMemsetAsync(e->STAG, 0, 2048 * 4, s));
+#ifdef LG_EXPERIMENTS
                 HIPCHK(e->tail_variant == 1 ? launch_tail4(prec, ta, s) : e->tail_variant == 2 ? launch_tail128(prec, ta, s) : e->tail_variant == 3 ? launch_tail32(prec, ta, s) : launch_tail(prec, ap, ta, s));
+#else
+                HIPCHK(launch_tail(prec, ap, ta, s));
+#endif
                 TRY(prof_end(e, s));
                 STEP_DONE(); STEP_DONE(); STEP_DONE(); STEP_DONE();
                 continue;

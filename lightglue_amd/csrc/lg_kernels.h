@@ -66,13 +66,13 @@ struct TailArgs {
     const float* gamma; const float* beta;   // LayerNorm(512)
     const void* W2; const float* b2;         // [256][512] fragment-packed, [256]
     long long* dbg;                          // profiling tap: [blocks][8 waves][8] shader-clock stamps, or nullptr
-    int* stag; int stag_delay;               // experiment (lg_tail4.hip): per-CU arrival counters [2048] + start delay (100 MHz ticks) of a CU's 2nd workgroup
     // optional: the NEXT block's q/k/v projection, run on the x tile this kernel has just produced (next.W == nullptr:
     // none).  next.X is unused; supported for 16-bit operand / attention precisions (launch_tail_supports_next).
     ProjArgs next;
 };
 bool launch_tail_supports_next(int prec, int attn_prec);
 hipError_t launch_tail(int prec, int attn_prec, const TailArgs& a, hipStream_t s);    // 8 waves, one workgroup per CU (lg_tail.hip)
+// experiment builds only (-DLG_EXPERIMENTS, lg_tail4.hip): streaming decompositions measured against the default, all slower
 hipError_t launch_tail4(int prec, const TailArgs& a, hipStream_t s);   // 4 waves x 64 rows, two workgroups per CU (lg_tail4.hip)
 hipError_t launch_tail128(int prec, const TailArgs& a, hipStream_t s); // 8 waves x 128 rows: half the weight stream per row (lg_tail4.hip)
 hipError_t launch_tail32(int prec, const TailArgs& a, hipStream_t s);  // 4 waves x 32 rows: twice the workgroups, for under-filled grids (lg_tail4.hip)

@@ -1,3 +1,4 @@
+// EXPERIMENT BUILDS ONLY (-DLG_EXPERIMENTS; not part of the product library).
 // lightglue_amd — fused block tail, streaming variants:  x <- x + ffn(cat[x, out_proj(ctx)])   (see lg_tail.hip for
 // the algebra, the reference lines and the weight packing; this file changes the workgroup decomposition only).
 //
@@ -95,14 +96,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void tailx_kernel(TailArg
         if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8 + slot] = clock64();
     };
     stamp(0);
-    if (a.stag_delay > 0) {   // experiment: anti-phase the two co-resident workgroups of a CU (MFMA phases of one under the VALU phases of the other)
-        if (tid == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF;
-            const int idx = atomicAdd(&a.stag[(xcc << 8) | ((hw >> 8) & 0xFF)], 1);
-            if (idx == 1) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < a.stag_delay) __builtin_amdgcn_s_sleep(64); }
-        }
-        __syncthreads();
-    }
     auto wfrag = [&](const void* base, int p, long long plane_elems, int nt, int kc) -> u32x4 {
         const char* ptr = static_cast<const char*>(base) + (p ? plane_elems * (long long)sizeof(typename Tag::elem) : 0);
         return *reinterpret_cast<const u32x4*>(ptr + ((long long)(nt * NKC + kc) * 64 + lane) * 16);

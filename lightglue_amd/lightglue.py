@@ -297,8 +297,14 @@ class LightGlue(nn.Module):
             _cabi.check(_cabi.load().lg_engine_reserve(h, batch, n0, n1))
 
     # ------------------------------------------------------------------ forward
+    def forward_raw(self, data: dict) -> dict:
+        """The forward without output widening, ragged lists or the host synchronisation: int32 `matches0/1` [B, M|N], fp32
+        `matching_scores0/1`, int32 `stop` [B] — views of the engine's own output buffers, valid on the current stream.  Used by
+        `PairShardedMatcher`, which puts exactly these on the wire (int32 is enough for N <= 4096; the API widens to int64)."""
+        return self.forward(data, _raw=True)
+
     @torch.no_grad()
-    def forward(self, data: dict) -> dict:
+    def forward(self, data: dict, _raw: bool = False) -> dict:
         """Match keypoints and descriptors between two images (same dict contract as ref :456-481).
 
         Input (dict):  image0/image1: {keypoints [B,N,2], descriptors [B,N,D], image_size [B,2] (optional),
@@ -399,6 +405,8 @@ class LightGlue(nn.Module):
         if getattr(self, "_debug_step", -1) >= 0:  # test tap: the pipeline stopped early, outputs are not written
             torch.cuda.synchronize(device)
             return None
+        if _raw:
+            return {"matches0": m0, "matches1": m1, "matching_scores0": ms0, "matching_scores1": ms1, "stop": stop_nm[0]}
         # ---- output assembly (ref :593-629).  Everything that does not need the ragged sizes is enqueued BEFORE
         # the one host synchronisation of the forward, so the GPU is never idle waiting for Python.
         i64 = ibuf.long()

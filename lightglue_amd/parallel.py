@@ -6,7 +6,10 @@ batch shards by contiguous blocks of pairs with NO data-path collective; one pro
 ``all_gather_into_tensor`` of a packed int32 buffer per batch (match indices; scores are carried as
 their fp32 bit patterns in the same buffer) — RCCL over xGMI on the GPU (backend "nccl"), gloo in
 the CPU tests.  Payload is a few MB at most, i.e. latency-bound on the xGMI ring; it is issued on the
-caller's stream right after the local forward.
+side stream right after the local forward (an event orders it behind the compute stream), so that the caller can start the
+next batch while the gather is on the wire (`issue_local` / `Pending.wait`; `forward` waits at once).  The HIP matcher hands
+over its int32 / fp32 output buffers as they are (`LightGlue.forward_raw`): no int64 round trip, no host synchronisation
+before the collective.
 
 The ragged ``matches`` lists are rebuilt from ``matches0`` after the gather (no variable-size
 collective).
@@ -68,6 +71,8 @@ class PairShardedMatcher:
     def __init__(self, matcher: Callable[[dict], dict], group=None):
         self.matcher = matcher
         self.group = group
+        self._src_cache: dict = {}
+        self._side = None      # side stream of the result gather (created on first use on a GPU)
 
     @property
     def world(self) -> int:
@@ -100,7 +105,22 @@ class PairShardedMatcher:
 
     __call__ = forward
 
-    def forward_local(self, local: dict, global_batch: int, shards: Optional[List[List[int]]] = None) -> Dict[str, torch.Tensor]:
+    def _row_source(self, shards: List[List[int]], per_rank: int, global_batch: int, device) -> torch.Tensor:
+        """gathered-buffer row of every pair of the batch (rank r's k-th row is pair shards[r][k]); built once per shard
+        assignment and kept on the device"""
+        key = (tuple(tuple(sh) for sh in shards), per_rank, str(device))
+        hit = self._src_cache.get(key)
+        if hit is None:
+            src = torch.empty(global_batch, dtype=torch.long)
+            for r, sh in enumerate(shards):
+                src[torch.tensor(sh, dtype=torch.long)] = r * per_rank + torch.arange(len(sh))
+            if len(self._src_cache) > 64:
+                self._src_cache.clear()
+            hit = self._src_cache[key] = src.to(device)
+        return hit
+
+    def issue_local(self, local: dict, global_batch: int, shards: Optional[List[List[int]]] = None) -> "Pending":
+        """Match the local shard and put the result gather in flight; `Pending.wait()` returns the full-batch dict."""
         m = local["image0"]["keypoints"].shape[1]
         n = local["image1"]["keypoints"].shape[1]
         world, rank = self.world, self.rank
@@ -109,41 +129,49 @@ class PairShardedMatcher:
         nloc = len(shards[rank])
         assert local["image0"]["keypoints"].shape[0] == nloc, "local shard size does not match the pair assignment"
         dev = local["image0"]["keypoints"].device
-        out = self.matcher(local) if nloc > 0 else None
+        raw = getattr(self.matcher, "forward_raw", None)
+        out = (raw(local) if raw is not None else self.matcher(local)) if nloc > 0 else None
         # ---- pack [pairs_max][2m + 2n + 1] int32: matches0 | bits(scores0) | matches1 | bits(scores1) | stop
         per_rank = (global_batch + world - 1) // world
         width = 2 * m + 2 * n + 1
-        buf = torch.zeros((per_rank, width), dtype=torch.int32, device=dev)
+        buf = torch.empty((per_rank, width), dtype=torch.int32, device=dev)
+        if nloc < per_rank:
+            buf[nloc:].zero_()
         if nloc > 0:
             stop = out["stop"]
             stop_t = torch.full((nloc,), int(stop), dtype=torch.int32, device=dev) if not torch.is_tensor(stop) else stop.to(dev, torch.int32).reshape(nloc)
-            buf[:nloc, 0:m] = out["matches0"].to(torch.int32)
+            as_i32 = lambda t: t if t.dtype is torch.int32 else t.to(torch.int32)
+            buf[:nloc, 0:m] = as_i32(out["matches0"])
             buf[:nloc, m:2 * m] = out["matching_scores0"].to(torch.float32).contiguous().view(torch.int32)
-            buf[:nloc, 2 * m:2 * m + n] = out["matches1"].to(torch.int32)
+            buf[:nloc, 2 * m:2 * m + n] = as_i32(out["matches1"])
             buf[:nloc, 2 * m + n:2 * m + 2 * n] = out["matching_scores1"].to(torch.float32).contiguous().view(torch.int32)
             buf[:nloc, -1] = stop_t
-        if world > 1:
-            # RCCL ("nccl") gathers device buffers directly; gloo (CPU tests, or a debugging run of several ranks
-            # on one GPU) goes through host copies
-            via_host = dist.get_backend(self.group) == "gloo" and buf.is_cuda
-            send = buf.cpu() if via_host else buf
-            gathered = torch.empty((world * per_rank, width), dtype=torch.int32, device=send.device)
-            dist.all_gather_into_tensor(gathered, send, group=self.group)
-            if via_host:
-                gathered = gathered.to(dev)
-            # rank r's k-th row is pair shards[r][k]: one gather of rows puts the batch back in input order
-            src = torch.empty(global_batch, dtype=torch.long)
-            for r, sh in enumerate(shards):
-                src[torch.tensor(sh, dtype=torch.long)] = r * per_rank + torch.arange(len(sh))
-            full = gathered.index_select(0, src.to(gathered.device))
-        else:
-            full = buf[:nloc]
-        m0 = full[:, 0:m].long()
-        ms0 = full[:, m:2 * m].contiguous().view(torch.float32)
-        m1 = full[:, 2 * m:2 * m + n].long()
-        ms1 = full[:, 2 * m + n:2 * m + 2 * n].contiguous().view(torch.float32)
-        stop = full[:, -1].long()
-        return {"matches0": m0, "matches1": m1, "matching_scores0": ms0, "matching_scores1": ms1, "stop": stop}
+        if world == 1:
+            return Pending(self, buf[:nloc], None, None, m, n)
+        # RCCL ("nccl") gathers device buffers directly; gloo (CPU tests, or a debugging run of several ranks
+        # on one GPU) goes through host copies
+        via_host = dist.get_backend(self.group) == "gloo" and buf.is_cuda
+        src = self._row_source(shards, per_rank, global_batch, dev)
+        if buf.is_cuda and not via_host:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            ready = torch.cuda.Event(); ready.record(torch.cuda.current_stream(dev))
+            gathered = torch.empty((world * per_rank, width), dtype=torch.int32, device=dev)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ready)
+                dist.all_gather_into_tensor(gathered, buf, group=self.group)
+                done = torch.cuda.Event(); done.record(self._side)
+            buf.record_stream(self._side); gathered.record_stream(self._side)
+            return Pending(self, gathered, src, done, m, n)
+        send = buf.cpu() if via_host else buf
+        gathered = torch.empty((world * per_rank, width), dtype=torch.int32, device=send.device)
+        dist.all_gather_into_tensor(gathered, send, group=self.group)
+        if via_host:
+            gathered = gathered.to(dev)
+        return Pending(self, gathered, src, None, m, n)
+
+    def forward_local(self, local: dict, global_batch: int, shards: Optional[List[List[int]]] = None) -> Dict[str, torch.Tensor]:
+        return self.issue_local(local, global_batch, shards).wait()
 
     @staticmethod
     def ragged(result: Dict[str, torch.Tensor]):
@@ -156,3 +184,20 @@ class PairShardedMatcher:
             matches.append(torch.stack([i0, result["matches0"][k][valid]], -1))
             scores.append(result["matching_scores0"][k][valid])
         return matches, scores
+
+
+class Pending:
+    """A result gather in flight.  `wait()` orders the current stream behind it and unpacks the full-batch tensors."""
+
+    def __init__(self, owner: PairShardedMatcher, gathered: torch.Tensor, src, done, m: int, n: int):
+        self.owner, self.gathered, self.src, self.done, self.m, self.n = owner, gathered, src, done, m, n
+
+    def wait(self) -> Dict[str, torch.Tensor]:
+        if self.done is not None:
+            torch.cuda.current_stream(self.gathered.device).wait_event(self.done)
+        full = self.gathered if self.src is None else self.gathered.index_select(0, self.src)
+        m, n = self.m, self.n
+        return {"matches0": full[:, 0:m].long(), "matches1": full[:, 2 * m:2 * m + n].long(),
+                "matching_scores0": full[:, m:2 * m].contiguous().view(torch.float32),
+                "matching_scores1": full[:, 2 * m + n:2 * m + 2 * n].contiguous().view(torch.float32),
+                "stop": full[:, -1].long()}

@@ -1,0 +1,101 @@
+"""PairShardedMatcher around the HIP LightGlue on ONE GPU (SURVEY.md §8e without an 8-GPU node): the RCCL path with a
+world of 1, and two ranks sharing cuda:0 over gloo — results must equal the plain model() bitwise, including a ragged batch
+dealt by the work-balanced (non-contiguous) assignment."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import gpu_util
+from conftest import require_gpu
+from lightglue_amd import PairShardedMatcher
+from lightglue_amd import synthetic as synth
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("matches0", "matches1", "matching_scores0", "matching_scores1")
+
+
+def _model():
+    return gpu_util.make_model(synth.make_state_dict(0, recipe="A"), "bf16x3", depth_confidence=-1, width_confidence=-1)
+
+
+def _batch(ragged):
+    t = gpu_util.to_torch(synth.make_batch(77, 5, 320, 288))
+    if ragged:
+        t["image0"]["num_keypoints"] = torch.tensor([320, 40, 300, 64, 129], dtype=torch.int32, device="cuda")
+        t["image1"]["num_keypoints"] = torch.tensor([288, 35, 200, 70, 288], dtype=torch.int32, device="cuda")
+    return t
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _check(res, plain):
+    for k in KEYS:
+        assert torch.equal(res[k], plain[k]), k
+    stop = plain["stop"] if torch.is_tensor(plain["stop"]) else torch.full((res["stop"].shape[0],), int(plain["stop"]))
+    assert torch.equal(res["stop"].cpu(), stop.cpu().long())
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_world_of_one_over_rccl_equals_plain_forward(ragged):
+    require_gpu()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        model = _model()
+        t = _batch(ragged)
+        plain = model(t)
+        sharded = PairShardedMatcher(model)
+        _check(sharded(t), plain)
+        pend = sharded.issue_local(t, 5)            # asynchronous form: gather in flight while the next forward runs
+        again = model(t)
+        _check(pend.wait(), plain)
+        assert torch.equal(again["matches0"], plain["matches0"])
+        matches, scores = PairShardedMatcher.ragged(sharded(t))
+        for b in range(5):
+            assert torch.equal(matches[b], plain["matches"][b]) and torch.equal(scores[b], plain["scores"][b])
+    finally:
+        dist.destroy_process_group()
+
+
+def _worker(rank, world, port, q, ragged):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sharded = PairShardedMatcher(_model())
+        t = _batch(ragged)
+        if ragged:
+            assert sharded.assignment(t) != [[0, 1, 2], [3, 4]], "the balanced assignment must be non-contiguous for this test"
+        res = sharded(t)
+        q.put((rank, {k: v.cpu().numpy() for k, v in res.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_two_ranks_sharing_one_gpu_equal_plain_forward(ragged):
+    require_gpu()
+    plain = _model()(_batch(ragged))
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, ragged)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        for k in KEYS:
+            np.testing.assert_array_equal(got[rank][k], plain[k].cpu().numpy(), err_msg=f"rank {rank} {k}")
+        np.testing.assert_array_equal(got[rank]["stop"], plain["stop"].cpu().numpy())

@@ -343,6 +343,9 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     };
     load_b_B(b2f[0], 0); load_b_B(b2f[1], 1); load_b_B(b2f[2], 2);
     gelu_store(0);
+#ifdef LG_GELU_UPFRONT
+    gelu_store(1); gelu_store(2); gelu_store(3);
+#endif
     __syncthreads();
     stamp(3);
     constexpr int CPS = NKC / 4;   // k-chunks per step (4 for 16-bit: K-stages 2j, 2j+1; 8 for f32)
@@ -363,10 +366,12 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             load_b_B(b2f[(kc + 3) & 3], kc + 3 < NKC ? kc + 3 : NKC - 1);
             chunk_B(kc, b2f[kc & 3]);
         }
+#ifndef LG_GELU_UPFRONT
         if (j < 3) {
             gelu_store(j + 1);
             __syncthreads();
         }
+#endif
     }
     stamp(4);
     // ------------------------------------------------------------------ epilogue: + b2, + x, store; next block's activation tile

@@ -49,7 +49,9 @@ CASES = {
     # cfg #4: DISK 128-d, N=M=4096
     "disk128_4096": dict(recipe="A", wseed=3, dseed=301, B=1, n=4096, m=4096, dim=128, conf=dict(depth_confidence=-1, width_confidence=-1, input_dim=128)),
     # cfg #5: ALIKED 128-d, 2048 x 512, pruning on with the 1536 threshold (only image0 can be pruned, ref :551/:559)
-    "aliked128_2048x512_prune1536": dict(recipe="B", wseed=2, dseed=401, B=2, n=2048, m=512, dim=128, prune_th=1536, conf=dict(input_dim=128)),
+    "aliked128_2048x512_prune1536": dict(recipe="C", wseed=2, dseed=401, B=2, n=2048, m=512, dim=128, prune_th=1536, conf=dict(input_dim=128)),
+    # cfg #3 with recipe C: the two pairs stop at DIFFERENT depths (3 and 9 layers) and are pruned at several layers
+    "adaptive_2048_th1536_mixed_depth": dict(recipe="C", wseed=0, dseed=201, B=2, n=2048, m=2048, dim=256, prune_th=1536, conf=dict()),
     # a18: the compiled path's semantics without torch.compile (ref :512-520, :529): inputs inside the static range are
     # padded with ones and masked, pruning off, early stop on; above the range nothing changes
     "static_lengths_256_512_in_range": dict(recipe="B", wseed=0, dseed=501, B=1, n=300, m=420, dim=256, prune_th=-1, static_lengths=[256, 512], conf=dict()),

@@ -258,6 +258,9 @@ def main():
     data_np = synthetic.make_batch(1 + rank * B, B, n, m)
     data = {k: {kk: torch.from_numpy(vv).to(dev) for kk, vv in v.items()} for k, v in data_np.items()}
     model.reserve(B, n, m, dev)
+    for kv in os.environ.get("LG_BENCH_OPTS", "").split():   # A/B of engine options (tools/ab_opt.sh), e.g. "tail_rows=64"
+        key, val = kv.split("=")
+        model.set_option(key, int(val), dev)
     if args.no_fuse_next:
         model.set_option("fused_next", 0, dev)
     if args.unfused:

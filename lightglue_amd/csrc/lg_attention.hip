@@ -218,20 +218,20 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
     auto sexp = [&](f32x4 (&s)[4][QT]) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            // exp2(s*c - m): packed fma (two scores per v_pk_fma_f32) + the bare v_exp_f32 (arguments <= 8, flush-to-zero tail
-            // is fine); row sums as packed adds
-            const f32x2 sc = {a.scale_log2e, a.scale_log2e}, nm = {-m_run[qt], -m_run[qt]};
-            f32x2 rs2 = {0.f, 0.f};
+            // exp2(s*c - m) with SCALAR v_fma_f32 / v_add_f32 and the bare v_exp_f32 (arguments <= 8, flush-to-zero tail is
+            // fine).  Packed f32 ops (v_pk_fma_f32 / v_pk_add_f32) are cheaper on their own but barely co-issue with another
+            // wave's MFMAs on the SIMD (tools/ubench/mfma_valu_overlap.hip: 24 % overlap vs 79 % for v_fma_f32), and this
+            // kernel lives on that overlap.  Two partial sums keep the add chain short.
+            const float sc = a.scale_log2e, nm = -m_run[qt];
+            float rs0 = 0.f, rs1 = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int h = 0; h < 4; h += 2) {
-                    const f32x2 e = f32x2{s[kt][qt][h], s[kt][qt][h + 1]} * sc + nm;
-                    const f32x2 p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
-                    s[kt][qt][h] = p[0]; s[kt][qt][h + 1] = p[1];
-                    rs2 += p;
-                }
-            l_run[qt] += rs2[0] + rs2[1];
+            for (int kt = 0; kt < 4; ++kt) {
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][0], sc, nm)), p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][1], sc, nm));
+                const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][2], sc, nm)), p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][3], sc, nm));
+                s[kt][qt][0] = p0; s[kt][qt][1] = p1; s[kt][qt][2] = p2; s[kt][qt][3] = p3;
+                rs0 += p0 + p2; rs1 += p1 + p3;
+            }
+            l_run[qt] += rs0 + rs1;
         }
     };
     // ---- O^T += V^T P^T with the V^T tile in LDS buffer `buf`

@@ -97,6 +97,7 @@ struct lg_engine {
     int attn_rows = 32;   // query rows per attention wave (32 | 64), option "attn_rows" / env LG_ATTN_ROWS
     int fused_tail = 1, fused_proj = 1, fused_next = 1, tail_variant = 0;   // tail_variant != 0: experiment builds only (lg_tail4.hip)
     int tail_timing = 0; long long* TAILDBG = nullptr;
+    int tail_rows = 0;   // 0 = automatic, 64 / 128 = force the fused tail's rows per workgroup (option "tail_rows")
     // ---- workspace
     void* ws = nullptr; size_t ws_bytes = 0;
     int capB = 0, cap0 = 0, cap1 = 0;      // reserved
@@ -511,6 +512,9 @@ int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
     if (std::strcmp(key, "tail_variant") == 0) return value == 0 ? LG_OK : fail(LG_ERR_INVALID, "tail_variant: the streaming tail variants are experiment builds only (-DLG_EXPERIMENTS)");
 #endif
     if (std::strcmp(key, "fused_proj") == 0) { e->fused_proj = value != 0; return LG_OK; }
+#ifdef LG_EXPERIMENTS
+    if (std::strcmp(key, "tail_rows") == 0) { if (value != 0 && value != 64 && value != 128) return fail(LG_ERR_INVALID, "tail_rows must be 0, 64 or 128"); e->tail_rows = value; return LG_OK; }
+#endif
     if (std::strcmp(key, "fused_next") == 0) { e->fused_next = value != 0; return LG_OK; }
     if (std::strcmp(key, "attn_rows") == 0) { if (value != 16 && value != 32 && value != 64) return fail(LG_ERR_INVALID, "attn_rows must be 16, 32 or 64"); e->attn_rows = value; return LG_OK; }
     if (std::strcmp(key, "profile_only") == 0) { e->prof_only = value; return LG_OK; }   // kernel class index, -1 = all classes
@@ -669,6 +673,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
     // layer boundary that is only valid when nothing re-orders rows in between (no early stop / pruning step).
     const bool fuse_next = e->fused_next && e->fused_tail && e->fused_proj && e->tail_variant == 0 && e->tail_timing == 0 &&
                            e->debug_stop < 0 && launch_tail_supports_next(prec, ap);
+    const bool prune_possible = do_prune && (n0 > e->cfg.pruning_min_kpts || n1 > e->cfg.pruning_min_kpts);
     bool proj_done = false;
     for (int i = 0; i < L; ++i) {
         for (int blk = 0; blk < 2; ++blk) {  // 0 = SelfBlock (ref :159-172), 1 = CrossBlock (ref :201-230)
@@ -711,13 +716,17 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 ta.W2 = (blk ? e->w_ctail_2 : e->w_stail_2) + (size_t)i * e->tail_2_layer_bytes;
                 ta.b2 = (blk ? e->b_cf2 : e->b_sf2) + (size_t)i * D;
                 ta.dbg = e->tail_timing == 1 ? e->TAILDBG : nullptr;
-                if (fuse_next && (blk == 0 || (i + 1 < L && !do_stop && !do_prune))) {
+                // Across a layer boundary the fusion is valid whenever no row can MOVE in between: early stop alone only
+                // deactivates a pair (its speculative projection is never read), pruning re-orders rows — but it cannot
+                // happen while every segment is at or below the pruning threshold (ref :551 / :559; lengths only shrink).
+                if (fuse_next && (blk == 0 || (i + 1 < L && !prune_possible))) {
                     ta.next = blk == 0 ? make_proj(i, 1) : make_proj(i + 1, 0);
                     proj_done = true;
                 }
                 TRY(prof_begin(e, PC_TAIL, s));
 #ifdef LG_EXPERIMENTS
-                HIPCHK(e->tail_variant == 1 ? launch_tail4(prec, ta, s) : e->tail_variant == 2 ? launch_tail128(prec, ta, s) : e->tail_variant == 3 ? launch_tail32(prec, ta, s) : launch_tail(prec, ap, ta, s));
+                if (e->tail_rows == 128 && prec == PREC_BF16X3 && ap == PREC_F16) HIPCHK(launch_tail_rows128(ta, s));   // lg_tail128.hip: +2 % time
+                else HIPCHK(e->tail_variant == 1 ? launch_tail4(prec, ta, s) : e->tail_variant == 2 ? launch_tail128(prec, ta, s) : e->tail_variant == 3 ? launch_tail32(prec, ta, s) : launch_tail(prec, ap, ta, s));
 #else
                 HIPCHK(launch_tail(prec, ap, ta, s));
 #endif
@@ -758,10 +767,11 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
             STEP_DONE();
         }
         if (i == L - 1) break;  // ref :544-545
-        if (do_stop || do_prune) {
+        const bool prune_now = do_prune && prune_possible;   // below the threshold the pruning branch is never taken (ref :551 / :559)
+        if (do_stop || prune_now) {
             RowDotArgs rd{};
             rd.rs = rs_act; rd.X = e->X;
-            if (do_stop && do_prune) {
+            if (do_stop && prune_now) {
                 rd.w0 = e->w_tok + (size_t)i * D; rd.b0 = e->b_tok + i; rd.out0 = e->CONF; rd.act0 = 1;
                 rd.w1 = e->w_match + (size_t)i * D; rd.b1 = e->b_match + i; rd.out1 = e->MSCORE; rd.act1 = 1;
             } else if (do_stop) {
@@ -782,7 +792,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
             ad.depth_conf = (float)e->cfg.depth_confidence;
             ad.width_conf = (float)(1.0 - e->cfg.width_confidence);
             ad.pruning_min_kpts = e->cfg.pruning_min_kpts;
-            ad.do_stop = do_stop; ad.do_prune = do_prune;
+            ad.do_stop = do_stop; ad.do_prune = prune_now;
             TRY(prof_begin(e, PC_ADAPTIVE, s));
             HIPCHK(launch_adapt(ad, s));
             TRY(prof_end(e, s));

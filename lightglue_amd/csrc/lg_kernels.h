@@ -71,6 +71,7 @@ struct TailArgs {
     ProjArgs next;
 };
 bool launch_tail_supports_next(int prec, int attn_prec);
+hipError_t launch_tail_rows128(const TailArgs& a, hipStream_t s);   // experiment builds: 128 rows per workgroup, PREC_BF16X3 + f16 attention only (lg_tail128.hip)
 hipError_t launch_tail(int prec, int attn_prec, const TailArgs& a, hipStream_t s);    // 8 waves, one workgroup per CU (lg_tail.hip)
 // experiment builds only (-DLG_EXPERIMENTS, lg_tail4.hip): streaming decompositions measured against the default, all slower
 hipError_t launch_tail4(int prec, const TailArgs& a, hipStream_t s);   // 4 waves x 64 rows, two workgroups per CU (lg_tail4.hip)

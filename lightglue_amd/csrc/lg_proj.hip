@@ -25,7 +25,7 @@ __global__ __launch_bounds__(PTHREADS) void proj_kernel(ProjArgs a) {
     const TileLoc t = locate_tile(a.rs, blockIdx.x, PBM);
     if (t.r0 >= a.rs.len[t.seg]) return;
     if (a.rs.active && !a.rs.active[t.pair]) return;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8] = clock64();   // profiling tap, slot 0
 
     // ---- activation tile: HBM -> registers -> operand precision -> LDS (once)

@@ -41,15 +41,15 @@ template <int PREC> struct PJL {   // LDS geometry of the activation tile
 //     [head][64][R] layout (4 consecutive rows of one channel).
 // Nothing is staged through LDS and no barrier follows the MFMA loop (the staged version spent 40 % of the kernel in its two
 // epilogues: LDS write, barrier, LDS read, store, barrier).
-template <int PREC, class TA, int NTP, int NPASS, int PASS, int A_PLANE>
+template <int PREC, class TA, int NTP, int NPASS, int PASS, int A_PLANE, int MT>
 __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, const char* smA, u32x4 (&bf)[PJ<PREC>::NPART == 2 ? 2 : 4][NTP][PJ<PREC>::NPART],
                                           int stamp_base) {
     typedef typename PJ<PREC>::Tag Tag;
     constexpr int NPART = PJ<PREC>::NPART;
-    constexpr int STAGES = PJL<PREC>::STAGES, NKC = 2 * STAGES, TILE = PJL<PREC>::TILE;
+    constexpr int STAGES = PJL<PREC>::STAGES, NKC = 2 * STAGES, TILE = MT * 16 * 128;   // one plane of one K stage: MT*16 rows x 128 B
     constexpr int NBUF = NPART == 2 ? 2 : 4;
     constexpr int N_QK = NTP == 3 ? 2 : 1;             // self: q, k, v groups of 256 columns; cross: qk, v
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, g = lane >> 4;
     const long long R = a.R;
     auto stamp = [&](int slot) {   // profiling tap (a.dbg == nullptr in production)
         if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8 + stamp_base + slot] = clock64();
@@ -64,9 +64,9 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
 #pragma unroll
             for (int p = 0; p < NPART; ++p) dst[j][p] = wfrag(p, w + 8 * (pass * NTP + j), kc);
     };
-    f32x4 acc[4][NTP];
+    f32x4 acc[MT][NTP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NTP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -80,32 +80,36 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
             load_b(bf[(i + NBUF - 1) % NBUF], npass, nk < NKC ? nk : nk - NKC);
             __builtin_amdgcn_sched_barrier(0);
             const char* tile = smA + (kc >> 1) * TILE;
-            u32x4 af[4][NPART];
+#pragma unroll
+            for (int mh = 0; mh < MT; mh += 4) {   // activation fragments of 4 row tiles at a time (bounds the live registers at MT = 8)
+            u32x4 afh[4][NPART];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int p = 0; p < NPART; ++p)
-                    af[mt][p] = *reinterpret_cast<const u32x4*>(tile + p * A_PLANE + lds_off<128>(mt * 16 + lr, (kc & 1) * 4 + g));
+                    afh[mt][p] = *reinterpret_cast<const u32x4*>(tile + p * A_PLANE + lds_off<128>((mh + mt) * 16 + lr, (kc & 1) * 4 + g));
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mtl = 0; mtl < 4; ++mtl)
 #pragma unroll
                 for (int j = 0; j < NTP; ++j) {
+                    const int mt = mh + mtl;
                     constexpr int dummy = 0; (void)dummy;
                     const bool is_v = ((PASS * NTP + j) >> 1) >= N_QK;     // compile-time after unrolling
                     if (is_v) {
                         if constexpr (NPART == 2) {
-                            mma_chunk<Tag>(acc[mt][j], af[mt][1], bf[i][j][0]);
-                            mma_chunk<Tag>(acc[mt][j], af[mt][0], bf[i][j][1]);
+                            mma_chunk<Tag>(acc[mt][j], afh[mtl][1], bf[i][j][0]);
+                            mma_chunk<Tag>(acc[mt][j], afh[mtl][0], bf[i][j][1]);
                         }
-                        mma_chunk<Tag>(acc[mt][j], af[mt][0], bf[i][j][0]);
+                        mma_chunk<Tag>(acc[mt][j], afh[mtl][0], bf[i][j][0]);
                     } else {
                         if constexpr (NPART == 2) {
-                            mma_chunk<Tag>(acc[mt][j], bf[i][j][0], af[mt][1]);
-                            mma_chunk<Tag>(acc[mt][j], bf[i][j][1], af[mt][0]);
+                            mma_chunk<Tag>(acc[mt][j], bf[i][j][0], afh[mtl][1]);
+                            mma_chunk<Tag>(acc[mt][j], bf[i][j][1], afh[mtl][0]);
                         }
-                        mma_chunk<Tag>(acc[mt][j], bf[i][j][0], af[mt][0]);
+                        mma_chunk<Tag>(acc[mt][j], bf[i][j][0], afh[mtl][0]);
                     }
                 }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -115,7 +119,7 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
     // every (tile, 16-row tile) iteration would expose one full L2 round trip (measured: 14k cycles for 12 iterations).
     typedef TA ta4 __attribute__((ext_vector_type(4)));
     f32x4 b4[NTP]; float bv[NTP];
-    f32x2 c2[NTP][4], s2[NTP][4];
+    f32x2 c2[NTP][MT], s2[NTP][MT];
 #pragma unroll
     for (int j = 0; j < NTP; ++j) {
         constexpr int dummy = 0; (void)dummy;
@@ -125,7 +129,7 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
             b4[j] = *reinterpret_cast<const f32x4*>(a.bias + col0 + 4 * g);
             if constexpr (NTP == 3) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     const long long row = t.grow0 + mt * 16 + lr;
                     c2[j][mt] = *reinterpret_cast<const f32x2*>(a.cosb + row * 32 + (d0 >> 1) + 2 * g);
                     s2[j][mt] = *reinterpret_cast<const f32x2*>(a.sinb + row * 32 + (d0 >> 1) + 2 * g);
@@ -148,7 +152,7 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
         if (group < N_QK) {                               // q / k (or qk): transposed tile
             TA* base = static_cast<TA*>(group == 0 ? a.q : a.k);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 const long long row = t.grow0 + mt * 16 + lr;
                 f32x4 v = acc[mt][j] + b4[j];
                 if constexpr (NTP == 3) {                 // SelfBlock: rotary, pairs (2f, 2f+1) with frequency f (ref :58-65)
@@ -162,7 +166,7 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
             }
         } else {                                          // v: plain tile -> transposed layout [head][64][R]
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 ta4 o = {pj_cvt<TA>(acc[mt][j][0] + bv[j]), pj_cvt<TA>(acc[mt][j][1] + bv[j]), pj_cvt<TA>(acc[mt][j][2] + bv[j]), pj_cvt<TA>(acc[mt][j][3] + bv[j])};
                 *reinterpret_cast<ta4*>(static_cast<TA*>(a.vt) + ((long long)head * 64 + d0 + lr) * R + t.grow0 + mt * 16 + 4 * g) = o;
             }
@@ -172,15 +176,15 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
 }
 
 // NTP = n-tiles per wave per pass: self (768 columns) 3 x 2 passes, cross (512 columns) 2 x 2.  A_PLANE = byte distance
-// between the hi and lo planes of the activation tile in LDS.
-template <int PREC, class TA, int NTP, int NPASS, int A_PLANE = PJL<PREC>::A_PLANE>
+// between the hi and lo planes of the activation tile in LDS; MT = 16-row tiles of the workgroup's row tile (4 or 8).
+template <int PREC, class TA, int NTP, int NPASS, int A_PLANE = PJL<PREC>::A_PLANE, int MT = 4>
 __device__ __forceinline__ void proj_compute(const ProjArgs& a, const TileLoc& t, const char* smA, int stamp_base) {
     static_assert(NPASS == 2, "two passes");
     typedef typename PJ<PREC>::Tag Tag;
     constexpr int NPART = PJ<PREC>::NPART;
     constexpr int NKC = 2 * PJL<PREC>::STAGES;
     constexpr int NBUF = NPART == 2 ? 2 : 4;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     u32x4 bf[NBUF][NTP][NPART];
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i)
@@ -193,8 +197,8 @@ __device__ __forceinline__ void proj_compute(const ProjArgs& a, const TileLoc& t
             }
     __syncthreads();   // the activation tile is complete
     if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8 + stamp_base + 1] = clock64();
-    proj_pass<PREC, TA, NTP, NPASS, 0, A_PLANE>(a, t, smA, bf, stamp_base);
-    proj_pass<PREC, TA, NTP, NPASS, 1, A_PLANE>(a, t, smA, bf, stamp_base);
+    proj_pass<PREC, TA, NTP, NPASS, 0, A_PLANE, MT>(a, t, smA, bf, stamp_base);
+    proj_pass<PREC, TA, NTP, NPASS, 1, A_PLANE, MT>(a, t, smA, bf, stamp_base);
 }
 
 }  // namespace lg

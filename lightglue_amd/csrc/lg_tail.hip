@@ -111,7 +111,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     const TileLoc t = locate_tile(a.rs, blockIdx.x, TBM);
     if (t.r0 >= a.rs.len[t.seg]) return;
     if (a.rs.active && !a.rs.active[t.pair]) return;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, g = lane >> 4;
     // optional per-phase shader-clock stamps (profiling tap; a.dbg == nullptr in production)
     auto stamp = [&](int slot) {
         if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8 + slot] = clock64();
@@ -172,49 +172,25 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     constexpr int NBUF = NPART == 2 ? 2 : 4;
     u32x4 bf[NBUF][4][NPART];   // ring of B fragments: this wave's 4 n-tiles x planes per k-chunk
     auto load_b_A = [&](u32x4 (&dst)[4][NPART], int kc) {
-#ifdef LG_AB_NOWLOAD   // ablation: no weight stream in phase A (fragments stay whatever the first loads brought)
-        if (kc >= NBUF) {
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int p = 0; p < NPART; ++p) asm volatile("" : "+v"(dst[nt][p]));
-            return;
-        }
-#endif
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int p = 0; p < NPART; ++p) dst[nt][p] = wfrag(Wc, p, 512LL * 512, w + 8 * nt, kc);
     };
-    auto chunk_A = [&](int kc, const u32x4 (&b)[4][NPART]) {   // one k-chunk of MFMAs against the LDS-resident tile
+    // activation fragments of one k-chunk (4 row tiles x planes) from the LDS-resident tile
+    auto read_af = [&](u32x4 (&af)[4][NPART], int kc) {
         const char* tile = smem + (kc >> 1) * TILE;
-        u32x4 af[4][NPART];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int p = 0; p < NPART; ++p) {
-#ifdef LG_AB_NOLDS     // ablation: no activation-fragment reads in phase A
-                af[mt][p] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; asm volatile("" : "+v"(af[mt][p]));
-#else
+            for (int p = 0; p < NPART; ++p)
                 af[mt][p] = *reinterpret_cast<const u32x4*>(tile + p * G_PLANE + lds_off<128>(mt * 16 + lr, (kc & 1) * 4 + g));
-#endif
-            }
-#ifdef LG_PRODUCT_MAJOR
-        if constexpr (NPART == 2) {   // product-major: 16 independent MFMAs per product, no back-to-back dependent pairs
-#pragma unroll
-            for (int pr = 0; pr < 3; ++pr)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) mma_chunk<Tag>(acc[mt][nt], b[nt][pr == 1 ? 1 : 0], af[mt][pr == 0 ? 1 : 0]);
-        } else
-#endif
-        {
+    };
+    auto mma_A = [&](const u32x4 (&af)[4][NPART], const u32x4 (&b)[4][NPART]) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) tail_mma<PREC>(acc[mt][nt], b[nt], af[mt]);
-        }
     };
     load_half(0);
 #pragma unroll
@@ -224,16 +200,23 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     load_half(1);                       // ctx rows stream in while the x half is multiplied
     __builtin_amdgcn_sched_barrier(0);
     constexpr int HC = NKC / 2;         // k-chunks per half
+    // The activation fragments of chunk kc + 1 are read from LDS BEFORE the MFMAs of chunk kc (two register sets): with
+    // the wave index provably uniform (SGPR address parts) the kernel has the 32 VGPRs for it, and the ~200-cycle LDS round
+    // trip at the head of every chunk — which both waves of a SIMD hit at the same time — disappears.  The prefetch stays
+    // inside a half (the other half is not in LDS yet); a half's first chunk reads its own.
+    u32x4 afr[2][4][NPART];
 #pragma unroll 1
     for (int hf = 0; hf < 2; ++hf) {
+        read_af(afr[0], hf * HC);
 #pragma unroll 1
         for (int c0 = 0; c0 < HC; c0 += NBUF) {
 #pragma unroll
             for (int i = 0; i < NBUF; ++i) {
                 const int kc = hf * HC + c0 + i;
                 load_b_A(bf[(i + NBUF - 1) % NBUF], kc + NBUF - 1 < NKC ? kc + NBUF - 1 : NKC - 1);
+                read_af(afr[(i + 1) & 1], c0 + i + 1 < HC ? kc + 1 : kc);
                 __builtin_amdgcn_sched_barrier(0);
-                chunk_A(kc, bf[i]);
+                mma_A(afr[i & 1], bf[i]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -343,9 +326,6 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     };
     load_b_B(b2f[0], 0); load_b_B(b2f[1], 1); load_b_B(b2f[2], 2);
     gelu_store(0);
-#ifdef LG_GELU_UPFRONT
-    gelu_store(1); gelu_store(2); gelu_store(3);
-#endif
     __syncthreads();
     stamp(3);
     constexpr int CPS = NKC / 4;   // k-chunks per step (4 for 16-bit: K-stages 2j, 2j+1; 8 for f32)
@@ -366,12 +346,10 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             load_b_B(b2f[(kc + 3) & 3], kc + 3 < NKC ? kc + 3 : NKC - 1);
             chunk_B(kc, b2f[kc & 3]);
         }
-#ifndef LG_GELU_UPFRONT
         if (j < 3) {
             gelu_store(j + 1);
             __syncthreads();
         }
-#endif
     }
     stamp(4);
     // ------------------------------------------------------------------ epilogue: + b2, + x, store; next block's activation tile

@@ -367,7 +367,9 @@ def test_fused_next_projection_is_bit_identical(precision):
     output must be BIT-identical with the option off — non-adaptive (both block boundaries fused) and adaptive
     (only SelfBlock -> CrossBlock fused, rows move between layers)."""
     require_gpu()
-    for recipe, kw in (("A", dict(depth_confidence=-1, width_confidence=-1)), ("B", dict(pruning_min_kpts=64))):
+    # third case: early stop on, pruning enabled but every image below the threshold (1536 by default) -> rows never move, the
+    # cross -> self projection is fused speculatively across the stop decision
+    for recipe, kw in (("A", dict(depth_confidence=-1, width_confidence=-1)), ("B", dict(pruning_min_kpts=64)), ("C", dict())):
         sd = synth.make_state_dict(0, recipe=recipe)
         data = gpu_util.to_torch(synth.make_batch(17, 3, 300, 333))
         model = gpu_util.make_model(sd, precision, **kw)

@@ -12,9 +12,12 @@ which = int(sys.argv[2]) if len(sys.argv) > 2 else 1   # 1 = fused tail, 2 = sel
 sd = synth.make_state_dict(0, recipe="A")
 model = gpu_util.make_model(sd, prec, depth_confidence=-1, width_confidence=-1)
 data = gpu_util.to_torch(synth.make_batch(1, 32, 1024, 1024))
+for kv in sys.argv[3:]:
+    k, v = kv.split("="); model.set_option(k, int(v))
 model(data); model.set_option("tail_timing", which); model(data); torch.cuda.synchronize()
 nst = 6
 d = model.debug_read("TAILDBG", np.int64).reshape(-1, 8, 8)[:, :, :nst]
+d = d[d[:, 0, 0] != 0]   # 128-row workgroups fill only half of the 64-row slots
 dt = np.diff(d, axis=2).astype(np.float64)
 names = ["phaseA", "LN", "GELU0", "phaseB+GELU", "epilogue"] if which == 1 else ["A tile -> LDS", "pass0 MFMA", "pass0 epilogue", "pass1 MFMA", "pass1 epilogue"]
 print(prec, "clock ticks per wave (median / p10 / p90) over", dt.shape[0], "blocks x 8 waves; s_memtime ticks at 100 MHz => x ~21 shader cycles")

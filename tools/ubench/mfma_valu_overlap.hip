@@ -75,7 +75,10 @@ template <int SCALAR> __global__ __launch_bounds__(512) void k(float* out, int i
         for (int i = 0; i < 8; ++i) v[i] = f32x2{0.01f * lane + i, 0.02f * lane - i};
         for (int it = 0; it < viters; ++it) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { if (SCALAR) { v[i][0] = gelu_fast1(v[i][0]) + 0.1f; v[i][1] = gelu_fast1(v[i][1]) + 0.1f; } else v[i] = gelu_fast2(v[i]) + 0.1f; }
+            for (int i = 0; i < 8; ++i) { if (SCALAR == 2) { v[i][0] = __builtin_amdgcn_exp2f(v[i][0]) ; v[i][1] = __builtin_amdgcn_exp2f(v[i][1]); v[i][0] = __builtin_amdgcn_exp2f(v[i][0]) ; v[i][1] = __builtin_amdgcn_exp2f(v[i][1]); }
+              else if (SCALAR == 3) { for (int q = 0; q < 8; ++q) { v[i][0] = __builtin_fmaf(v[i][0], 0.999f, 0.001f); v[i][1] = __builtin_fmaf(v[i][1], 1.001f, -0.001f); } }
+              else if (SCALAR == 4) { for (int q = 0; q < 8; ++q) v[i] = v[i] * f32x2{0.999f, 1.001f} + f32x2{0.001f, -0.001f}; }
+              else if (SCALAR) { v[i][0] = gelu_fast1(v[i][0]) + 0.1f; v[i][1] = gelu_fast1(v[i][1]) + 0.1f; } else v[i] = gelu_fast2(v[i]) + 0.1f; }
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) s += v[i][0] + v[i][1];
@@ -97,9 +100,12 @@ int main() {
     const int iters = 2000;
     const float tm = run<0>(d, iters, 1, 0);
     printf("MFMA waves alone (1 per SIMD): %.3f ms  (%.0f TF)\n", tm, 256.0 * 4 * iters * 48 * 16384.0 / tm / 1e9);
-    for (int viters : {1000, 2000, 4000}) {
+    for (int viters : {2000}) {
         const float tv1 = run<1>(d, iters, 2, viters), tb1 = run<1>(d, iters, 3, viters);
         printf("scalar VALU iters %d: VALU alone %.3f ms, both %.3f ms  (sum %.3f, max %.3f) -> overlap efficiency %.2f\n", viters, tv1, tb1, tm + tv1, fmaxf(tm, tv1), (tm + tv1 - tb1) / fminf(tm, tv1));
+        { const float a = run<2>(d, iters, 2, viters * 4), b = run<2>(d, iters, 3, viters * 4); printf("v_exp_f32 only   x%d: alone %.3f both %.3f -> overlap %.2f\n", viters * 4, a, b, (tm + a - b) / fminf(tm, a)); }
+        { const float a = run<3>(d, iters, 2, viters), b = run<3>(d, iters, 3, viters); printf("v_fma_f32 only   x%d: alone %.3f both %.3f -> overlap %.2f\n", viters, a, b, (tm + a - b) / fminf(tm, a)); }
+        { const float a = run<4>(d, iters, 2, viters), b = run<4>(d, iters, 3, viters); printf("v_pk_fma_f32 only x%d: alone %.3f both %.3f -> overlap %.2f\n", viters, a, b, (tm + a - b) / fminf(tm, a)); }
         const float tv = run<0>(d, iters, 2, viters), tb = run<0>(d, iters, 3, viters);
         printf("packed VALU iters %d: VALU alone %.3f ms, both %.3f ms  (sum %.3f, max %.3f) -> overlap efficiency %.2f\n", viters, tv, tb, tm + tv, fmaxf(tm, tv), (tm + tv - tb) / fminf(tm, tv));
     }

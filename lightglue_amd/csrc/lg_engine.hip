@@ -63,6 +63,17 @@ inline uint16_t f32_to_f16(float f) {
     return (uint16_t)(sign | out);
 }
 
+inline float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) u = sign;
+        else { int sh = 0; uint32_t mm = m; while (!(mm & 0x400u)) { mm <<= 1; ++sh; } u = sign | ((uint32_t)(127 - 15 - sh + 1) << 23) | ((mm & 0x3ffu) << 13); }
+    } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+    else u = sign | ((e + 112u) << 23) | (m << 13);
+    float f; std::memcpy(&f, &u, 4); return f;
+}
+
 struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
 
 // A device weight matrix [rows][K] in operand precision (+ lo half for split bf16)
@@ -143,7 +154,8 @@ int upload_packed(int prec, const float* src, size_t n, PackedW& dst, size_t ele
 }
 
 // MFMA-fragment order (lg_kernels.h TailArgs): plane-major, then [n-tile][k-chunk][lane][EPC]
-int upload_fragment_packed(int prec, const std::vector<double>& W, int rows, int K, char* dst) {
+// split_f16: hi = f16(v), lo = f16(v - hi) planes (the q/k/v projection weights of the default precision, lg_proj_body.h)
+int upload_fragment_packed(int prec, const std::vector<double>& W, int rows, int K, char* dst, bool split_f16 = false) {
     const size_t es = elem_size(prec);
     const int EPC = prec == PREC_F32 ? 4 : 8, KC = 4 * EPC, NKC = K / KC, NT = rows / 16;
     const bool split = prec == PREC_BF16X3;
@@ -157,7 +169,11 @@ int upload_fragment_packed(int prec, const std::vector<double>& W, int rows, int
                     const size_t idx = ((size_t)(nt * NKC + kc) * 64 + lane) * EPC + j;
                     if (prec == PREC_F32) reinterpret_cast<float*>(buf.data())[idx] = v;
                     else if (prec == PREC_F16) reinterpret_cast<uint16_t*>(buf.data())[idx] = f32_to_f16(v);
-                    else {
+                    else if (split_f16) {
+                        const uint16_t h = f32_to_f16(v);
+                        reinterpret_cast<uint16_t*>(buf.data())[idx] = h;
+                        reinterpret_cast<uint16_t*>(buf.data())[n + idx] = f32_to_f16(v - f16_to_f32(h));
+                    } else {
                         const uint16_t h = f32_to_bf16(v);
                         reinterpret_cast<uint16_t*>(buf.data())[idx] = h;
                         if (split) reinterpret_cast<uint16_t*>(buf.data())[n + idx] = f32_to_bf16(v - bf16_to_f32(h));
@@ -418,7 +434,7 @@ int lg_engine_finalize_weights(lg_engine* e) {
                 pb[dst] = b->data[src];
             }
             TRY(upload_packed(prec, pw.data(), pw.size(), e->w_sqkv, (size_t)i * 768 * D));
-            TRY(upload_fragment_packed(prec, std::vector<double>(pw.begin(), pw.end()), 768, D, e->w_sqkv_p + (size_t)i * sqkv_layer));
+            TRY(upload_fragment_packed(prec, std::vector<double>(pw.begin(), pw.end()), 768, D, e->w_sqkv_p + (size_t)i * sqkv_layer, prec == PREC_BF16X3));
             TRY(up_f32(e->b_sqkv + (size_t)i * 768, pb.data(), 768));
         }
         {
@@ -472,7 +488,7 @@ int lg_engine_finalize_weights(lg_engine* e) {
             std::memcpy(pw.data() + (size_t)D * D, wv->data.data(), (size_t)D * D * 4);
             std::memcpy(pb.data(), bq->data.data(), D * 4); std::memcpy(pb.data() + D, bv->data.data(), D * 4);
             TRY(upload_packed(prec, pw.data(), pw.size(), e->w_cqkv, (size_t)i * 512 * D));
-            TRY(upload_fragment_packed(prec, std::vector<double>(pw.begin(), pw.end()), 512, D, e->w_cqkv_p + (size_t)i * cqkv_layer));
+            TRY(upload_fragment_packed(prec, std::vector<double>(pw.begin(), pw.end()), 512, D, e->w_cqkv_p + (size_t)i * cqkv_layer, prec == PREC_BF16X3));
             TRY(up_f32(e->b_cqkv + (size_t)i * 512, pb.data(), 512));
             TRY(upload_packed(prec, wo->data.data(), (size_t)D * D, e->w_cout, (size_t)i * D * D));
             TRY(up_f32(e->b_cout + (size_t)i * D, bo->data.data(), D));

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(PTHREADS) void proj_kernel(ProjArgs a) {
                 split8_bf16(hreg[st][0], hreg[st][1], hi, lo);
                 *reinterpret_cast<u32x4*>(tile + off) = hi;
                 *reinterpret_cast<u32x4*>(tile + A_PLANE + off) = lo;
-            } else {
+            } else {   // single plane (PREC_QKV_F16W2: one f16 plane)
                 *reinterpret_cast<u32x4*>(tile + off) = pack8<Tag>(hreg[st][0], hreg[st][1]);
             }
         }
@@ -83,7 +83,7 @@ hipError_t launch_proj(int prec, int attn_prec, const ProjArgs& a, hipStream_t s
         case PREC_F32: return launch_proj_p<PREC_F32>(attn_prec, a, s);
         case PREC_BF16: return launch_proj_p<PREC_BF16>(attn_prec, a, s);
         case PREC_F16: return launch_proj_p<PREC_F16>(attn_prec, a, s);
-        case PREC_BF16X3: return launch_proj_p<PREC_BF16X3>(attn_prec, a, s);
+        case PREC_BF16X3: return launch_proj_p<PREC_QKV_F16W2>(attn_prec, a, s);   // f16 activations x split-f16 weights (lg_proj_body.h)
     }
     return hipErrorInvalidValue;
 }

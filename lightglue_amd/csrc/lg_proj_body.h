@@ -11,11 +11,29 @@ namespace lg {
 
 constexpr int PBM = 64, PTHREADS = 512;
 
+// Operand scheme of the projection.  NPART = weight planes, APART = activation planes.
+// PREC_QKV_F16W2 is what the default precision ("bf16x3") uses for the q/k/v projections: the activation tile as ONE f16
+// plane, the weights as split f16 (hi + lo), i.e. TWO MFMAs per product instead of the three of split-bf16.  q/k/v leave
+// this kernel rounded to f16 for the attention anyway, so rounding x to f16 first costs nothing measurable (oracle study,
+// max |dscore| 2.3-3.0e-4 vs 2.2-2.5e-4 for split-bf16; a single f16 product would give 1.0-1.6e-3).
+constexpr int PREC_QKV_F16W2 = 100;
 template <int PREC> struct PJ;
-template <> struct PJ<PREC_F32> { typedef TagF32 Tag; static constexpr int NPART = 1; };
-template <> struct PJ<PREC_BF16> { typedef TagBF16 Tag; static constexpr int NPART = 1; };
-template <> struct PJ<PREC_F16> { typedef TagF16 Tag; static constexpr int NPART = 1; };
-template <> struct PJ<PREC_BF16X3> { typedef TagBF16 Tag; static constexpr int NPART = 2; };
+template <> struct PJ<PREC_F32> { typedef TagF32 Tag; static constexpr int NPART = 1, APART = 1; };
+template <> struct PJ<PREC_BF16> { typedef TagBF16 Tag; static constexpr int NPART = 1, APART = 1; };
+template <> struct PJ<PREC_F16> { typedef TagF16 Tag; static constexpr int NPART = 1, APART = 1; };
+template <> struct PJ<PREC_BF16X3> { typedef TagBF16 Tag; static constexpr int NPART = 2, APART = 2; };
+template <> struct PJ<PREC_QKV_F16W2> { typedef TagF16 Tag; static constexpr int NPART = 2, APART = 1; };
+
+// acc += product of one weight fragment set (NPART planes) and one activation fragment set (APART planes).  TRANSPOSED: the
+// weights are the A operand.  split x split: hi*lo + lo*hi + hi*hi; split weights x single activation: lo*x + hi*x.
+template <int PREC, bool TRANSPOSED>
+__device__ __forceinline__ void pj_mma(f32x4& acc, const u32x4* wf, const u32x4* xf) {
+    typedef typename PJ<PREC>::Tag Tag;
+    auto mm = [&](const u32x4& wv, const u32x4& xv) { if constexpr (TRANSPOSED) mma_chunk<Tag>(acc, wv, xv); else mma_chunk<Tag>(acc, xv, wv); };
+    if constexpr (PJ<PREC>::NPART == 2 && PJ<PREC>::APART == 2) { mm(wf[0], xf[1]); mm(wf[1], xf[0]); mm(wf[0], xf[0]); }
+    else if constexpr (PJ<PREC>::NPART == 2) { mm(wf[1], xf[0]); mm(wf[0], xf[0]); }
+    else mm(wf[0], xf[0]);
+}
 
 template <class T> __device__ __forceinline__ T pj_cvt(float x);
 template <> __device__ __forceinline__ float pj_cvt<float>(float x) { return x; }
@@ -28,7 +46,7 @@ template <int PREC> struct PJL {   // LDS geometry of the activation tile
     static constexpr int STAGES = 256 / KE;            // 4 (16-bit) or 8 (f32)
     static constexpr int TILE = PBM * 128;             // one plane of one stage
     static constexpr int A_PLANE = STAGES * TILE;      // 32 KB (16-bit) / 64 KB (f32)
-    static constexpr int A_BYTES = PJ<PREC>::NPART * A_PLANE;
+    static constexpr int A_BYTES = PJ<PREC>::APART * A_PLANE;
 };
 // One pass of the projection: NTP n-tiles per wave (wave w owns the n-tiles w + 8*jj, jj = PASS*NTP + j, i.e. the 16 output
 // columns w*16 + 128*jj ...).  The column group of a tile (q / k / v, or qk / v) is jj >> 1 — a compile-time constant — and decides
@@ -45,7 +63,7 @@ template <int PREC, class TA, int NTP, int NPASS, int PASS, int A_PLANE, int MT>
 __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, const char* smA, u32x4 (&bf)[PJ<PREC>::NPART == 2 ? 2 : 4][NTP][PJ<PREC>::NPART],
                                           int stamp_base) {
     typedef typename PJ<PREC>::Tag Tag;
-    constexpr int NPART = PJ<PREC>::NPART;
+    constexpr int NPART = PJ<PREC>::NPART, APART = PJ<PREC>::APART;
     constexpr int STAGES = PJL<PREC>::STAGES, NKC = 2 * STAGES, TILE = MT * 16 * 128;   // one plane of one K stage: MT*16 rows x 128 B
     constexpr int NBUF = NPART == 2 ? 2 : 4;
     constexpr int N_QK = NTP == 3 ? 2 : 1;             // self: q, k, v groups of 256 columns; cross: qk, v
@@ -82,32 +100,20 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
             const char* tile = smA + (kc >> 1) * TILE;
 #pragma unroll
             for (int mh = 0; mh < MT; mh += 4) {   // activation fragments of 4 row tiles at a time (bounds the live registers at MT = 8)
-            u32x4 afh[4][NPART];
+            u32x4 afh[4][APART];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int p = 0; p < NPART; ++p)
+                for (int p = 0; p < APART; ++p)
                     afh[mt][p] = *reinterpret_cast<const u32x4*>(tile + p * A_PLANE + lds_off<128>((mh + mt) * 16 + lr, (kc & 1) * 4 + g));
 #pragma unroll
             for (int mtl = 0; mtl < 4; ++mtl)
 #pragma unroll
                 for (int j = 0; j < NTP; ++j) {
-                    const int mt = mh + mtl;
                     constexpr int dummy = 0; (void)dummy;
                     const bool is_v = ((PASS * NTP + j) >> 1) >= N_QK;     // compile-time after unrolling
-                    if (is_v) {
-                        if constexpr (NPART == 2) {
-                            mma_chunk<Tag>(acc[mt][j], afh[mtl][1], bf[i][j][0]);
-                            mma_chunk<Tag>(acc[mt][j], afh[mtl][0], bf[i][j][1]);
-                        }
-                        mma_chunk<Tag>(acc[mt][j], afh[mtl][0], bf[i][j][0]);
-                    } else {
-                        if constexpr (NPART == 2) {
-                            mma_chunk<Tag>(acc[mt][j], bf[i][j][0], afh[mtl][1]);
-                            mma_chunk<Tag>(acc[mt][j], bf[i][j][1], afh[mtl][0]);
-                        }
-                        mma_chunk<Tag>(acc[mt][j], bf[i][j][0], afh[mtl][0]);
-                    }
+                    if (is_v) pj_mma<PREC, false>(acc[mh + mtl][j], bf[i][j], afh[mtl]);
+                    else pj_mma<PREC, true>(acc[mh + mtl][j], bf[i][j], afh[mtl]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);

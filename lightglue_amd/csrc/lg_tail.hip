@@ -369,10 +369,8 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             if constexpr (NEXT != 0) {
                 static_assert(EPC == 8, "fused next projection: 16-bit operands only");
                 char* dst = smem + (col >> 6) * TILE + lds_off<128>(row, (col & 63) >> 3) + (col & 7) * 2;
-                if constexpr (PREC == PREC_BF16X3) {
-                    const float h0 = bf16_round(xn[0]), h1 = bf16_round(xn[1]), h2 = bf16_round(xn[2]), h3 = bf16_round(xn[3]);
-                    *reinterpret_cast<u32x2*>(dst) = u32x2{pack2_bf16(h0, h1), pack2_bf16(h2, h3)};
-                    *reinterpret_cast<u32x2*>(dst + G_PLANE) = u32x2{pack2_bf16(xn[0] - h0, xn[1] - h1), pack2_bf16(xn[2] - h2, xn[3] - h3)};
+                if constexpr (PREC == PREC_BF16X3) {   // the projection takes ONE f16 plane (PREC_QKV_F16W2, lg_proj_body.h)
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{pack2_f16(xn[0], xn[1]), pack2_f16(xn[2], xn[3])};
                 } else {
                     *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<Tag>(xn[0], xn[1]), pack2<Tag>(xn[2], xn[3])};
                 }
@@ -380,7 +378,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         }
     }
     stamp(5);
-    if constexpr (NEXT != 0) proj_compute<PREC, TA, NEXT == 1 ? 3 : 2, 2, G_PLANE>(a.next, t, smem, 8);
+    if constexpr (NEXT != 0) proj_compute<(PREC == PREC_BF16X3 ? PREC_QKV_F16W2 : PREC), TA, NEXT == 1 ? 3 : 2, 2, G_PLANE>(a.next, t, smem, 8);
 }
 
 template <int PREC, int NEXT, class TA> static hipError_t launch_tail_t(const TailArgs& a, hipStream_t s) {

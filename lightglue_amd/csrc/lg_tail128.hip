@@ -269,14 +269,12 @@ __global__ __launch_bounds__(T8THREADS) void tail128_kernel(TailArgs a) {
             if (t.r0 + row < qlen) *reinterpret_cast<f32x4*>(a.X + (long long)(t.grow0 + row) * 256 + col) = xn;
             if constexpr (NEXT != 0) {
                 char* dst = smem + (col >> 6) * T8_TILE + lds_off<128>(row, (col & 63) >> 3) + (col & 7) * 2;
-                const float h0 = bf16_round(xn[0]), h1 = bf16_round(xn[1]), h2 = bf16_round(xn[2]), h3 = bf16_round(xn[3]);
-                *reinterpret_cast<u32x2*>(dst) = u32x2{pack2_bf16(h0, h1), pack2_bf16(h2, h3)};
-                *reinterpret_cast<u32x2*>(dst + 4 * T8_TILE) = u32x2{pack2_bf16(xn[0] - h0, xn[1] - h1), pack2_bf16(xn[2] - h2, xn[3] - h3)};
+                *reinterpret_cast<u32x2*>(dst) = u32x2{pack2_f16(xn[0], xn[1]), pack2_f16(xn[2], xn[3])};
             }
         }
     }
     stamp(5);
-    if constexpr (NEXT != 0) proj_compute<PREC_BF16X3, f16_t, NEXT == 1 ? 3 : 2, 2, 4 * T8_TILE, 8>(a.next, t, smem, 8);
+    if constexpr (NEXT != 0) proj_compute<PREC_QKV_F16W2, f16_t, NEXT == 1 ? 3 : 2, 2, 4 * T8_TILE, 8>(a.next, t, smem, 8);
 }
 
 template <int NEXT> static hipError_t launch_tail128_t(const TailArgs& a, hipStream_t s) {

@@ -96,12 +96,23 @@ def round_bf16x2(x: np.ndarray) -> np.ndarray:
     return hi + round_bf16(x - hi)
 
 
-_ROUNDERS = {None: lambda a: a, "fp32": lambda a: a, "bf16": round_bf16, "fp16": round_fp16, "bf16x2": round_bf16x2}
+def round_fp16x2(x: np.ndarray) -> np.ndarray:
+    """hi + lo with both fp16 (split-f16 weights of the q/k/v projections in the HIP path's default precision)."""
+    hi = round_fp16(x)
+    return hi + round_fp16(x - hi)
+
+
+_ROUNDERS = {None: lambda a: a, "fp32": lambda a: a, "bf16": round_bf16, "fp16": round_fp16, "bf16x2": round_bf16x2, "fp16x2": round_fp16x2}
+
+# operand rounding of the HIP path's default precision ("bf16x3"), for emulation studies: split-bf16 linear layers, f16
+# attention, and the q/k/v projections as f16 activations x split-f16 weights (two MFMAs per product; q/k/v are rounded to f16
+# for the attention anyway)
+DEFAULT_PRECISION_QUANT = {"lin": "bf16x2", "attn": "fp16", "final": "bf16x2", "lin_qkv": ("fp16", "fp16x2")}
 
 
 class _Ctx:
     """``quant``: None | mode | {"lin": mode, "attn"|"attn_qk"/"attn_pv": mode, "final": mode} with
-    mode in None/"fp32"/"bf16"/"fp16"/"bf16x2": operand rounding per contraction class (linear
+    mode in None/"fp32"/"bf16"/"fp16"/"bf16x2"/"fp16x2" or an (activation, weight) tuple: operand rounding per contraction class (linear
     layers, attention QK^T / PV, final projection + similarity)."""
 
     def __init__(self, dtype, quant):

@@ -55,8 +55,11 @@ def test_operand_rounding_emulation_orders():
     sd, data = make_golden.case_inputs(meta["case"])
     conf = oracle_conf_for(meta["case"])
     e = {}
-    for q in ("bf16", {"lin": "bf16x2", "attn": "fp16", "final": "bf16x2"}):
+    # plain bf16 | the HIP path's default precision | the same with the q/k/v projections as ONE f16 product (rejected: over the bar
+    # at N = 1024) — the per-contraction allocation of DESIGN.md §1
+    for q in ("bf16", O.DEFAULT_PRECISION_QUANT, {**O.DEFAULT_PRECISION_QUANT, "lin_ffn3": ("fp16", "fp32")}):
         out = O.forward(sd, conf, data, quant=q)
         e[str(q)] = np.abs(out["matching_scores0"] - gold["matching_scores0"]).max()
     vals = list(e.values())
     assert vals[1] < 1e-3 < vals[0], e
+    assert vals[2] > 2 * vals[1], e      # g in one f16 plane (2 products for ffn.3) costs several times the error: not taken

@@ -152,6 +152,21 @@ int lg_sp_sample_descriptors(const float* desc_map, int32_t batch, int32_t chann
                              const float* keypoints, const int32_t* num, int32_t n, int32_t cell,
                              int32_t normalize_dense, float* workspace, float* out, void* hip_stream);
 
+/* ---- SuperPoint conv stack (replaces superpoint.py:127-141 layers and :159-184, :213-214 of forward) ----
+ * lg_sp_pack_conv_weight: repack one nn.Conv2d weight [cout][cin][k][k] (device fp32) into the layout the kernels read,
+ *   [k*k][cout][cin] (conv1a: [9][64]); dst holds cout*cin*k*k floats.
+ * lg_sp_encode: image [batch][1][h][w] fp32 (grayscale, h and w multiples of 8) ->
+ *   scores   [batch][h][w]            keypoint probabilities after softmax / dustbin removal / depth-to-space (ref :176-184),
+ *                                      the input of lg_sp_detect
+ *   desc_map [batch][256][h/8][w/8]   RAW convDb output (NCHW), the input of lg_sp_sample_descriptors(normalize_dense = 1)
+ *   params: 24 device pointers = (packed weight, bias) of conv1a, conv1b, conv2a, conv2b, conv3a, conv3b, conv4a, conv4b,
+ *           convPa, convPb, convDa, convDb; workspace: lg_sp_encode_workspace_bytes(batch, h, w) bytes.
+ * Exact fp32 arithmetic (f32 MFMA): scores agree with an fp32 convolution to round-off. */
+int lg_sp_pack_conv_weight(const float* src, int32_t cout, int32_t cin, int32_t k, float* dst, void* hip_stream);
+int64_t lg_sp_encode_workspace_bytes(int32_t batch, int32_t h, int32_t w);
+int lg_sp_encode(const float* image, int32_t batch, int32_t h, int32_t w, const float* const* params, void* workspace,
+                 int64_t workspace_bytes, float* scores, float* desc_map, void* hip_stream);
+
 /* Keypoint extraction from SuperPoint's dense score map: replaces simple_nms (lightglue/superpoint.py:52-70), the
  * border removal, thresholding, per-image split (:186-204), top_k_keypoints (:73-77, :207-215) and the (y, x) -> (x, y)
  * float conversion (:218).  Bit-identical to the reference (all comparisons are exact; ties inside top-k, which

@@ -563,6 +563,27 @@ SpLayout sp_layout(int B, int h, int w, int maxc) {
 }
 }  // namespace
 
+int lg_sp_pack_conv_weight(const float* src, int32_t cout, int32_t cin, int32_t k, float* dst, void* hip_stream) {
+    if (!src || !dst || cout < 1 || cin < 1 || (k != 1 && k != 3)) return fail(LG_ERR_INVALID, "bad conv weight");
+    HIPCHK(launch_sp_pack_weight(src, dst, cout, cin, k, static_cast<hipStream_t>(hip_stream)));
+    return LG_OK;
+}
+
+int64_t lg_sp_encode_workspace_bytes(int32_t batch, int32_t h, int32_t w) {
+    if (batch < 1 || h < 8 || w < 8) return 0;
+    return (int64_t)2 * batch * h * w * 64 * 4;
+}
+
+int lg_sp_encode(const float* image, int32_t batch, int32_t h, int32_t w, const float* const* params, void* workspace,
+                 int64_t workspace_bytes, float* scores, float* desc_map, void* hip_stream) {
+    if (batch < 1 || h < 8 || w < 8 || (h & 7) || (w & 7)) return fail(LG_ERR_INVALID, "image height / width must be positive multiples of 8");
+    if (!image || !params || !workspace || !scores || !desc_map) return fail(LG_ERR_INVALID, "null pointer");
+    if (workspace_bytes < lg_sp_encode_workspace_bytes(batch, h, w)) return fail(LG_ERR_INVALID, "workspace too small (lg_sp_encode_workspace_bytes)");
+    for (int i = 0; i < 24; ++i) if (!params[i]) return fail(LG_ERR_INVALID, "null layer parameter");
+    HIPCHK(launch_sp_encode(image, batch, h, w, params, static_cast<float*>(workspace), scores, desc_map, static_cast<hipStream_t>(hip_stream)));
+    return LG_OK;
+}
+
 int64_t lg_sp_detect_workspace_bytes(int32_t batch, int32_t h, int32_t w, int32_t max_candidates) {
     if (batch < 1 || h < 1 || w < 1 || max_candidates < 1) return 0;
     return (int64_t)sp_layout(batch, h, w, max_candidates).total;

@@ -101,8 +101,103 @@ def reference_detect(ref, scores: torch.Tensor, nms_radius=4, remove_borders=4, 
     return keypoints, list(sc)
 
 
+# full extractor (conv stack included): name -> (weight seed, image seed, B, H, W, max_num_keypoints)
+ENCODE_CASES = {
+    "superpoint_full_b1_120x160": (0, 10, 1, 120, 160, None),
+    "superpoint_full_b2_64x96_top50": (1, 11, 2, 64, 96, 50),
+}
+
+
+def encoder_state_dict(seed: int):
+    """Seeded weights with the reference's names / shapes (ref superpoint.py:127-141): nn.Conv2d default init ranges, the
+    keypoint logits scaled up so that the softmax is far from uniform (peaky score maps like the trained network's)."""
+    g = torch.Generator().manual_seed(seed)
+    shapes = [("conv1a", 64, 1, 3), ("conv1b", 64, 64, 3), ("conv2a", 64, 64, 3), ("conv2b", 64, 64, 3), ("conv3a", 128, 64, 3),
+              ("conv3b", 128, 128, 3), ("conv4a", 128, 128, 3), ("conv4b", 128, 128, 3), ("convPa", 256, 128, 3), ("convPb", 65, 256, 1),
+              ("convDa", 256, 128, 3), ("convDb", 256, 256, 1)]
+    sd = {}
+    for name, co, ci, k in shapes:
+        bound = 1.0 / np.sqrt(ci * k * k)
+        gain = 3.0 if name != "convPb" else 1.5       # keep activations alive through 10 ReLU layers; spread the logits
+        sd[name + ".weight"] = (torch.rand((co, ci, k, k), generator=g) * 2 - 1) * bound * gain
+        sd[name + ".bias"] = (torch.rand((co,), generator=g) * 2 - 1) * bound
+    return sd
+
+
+def encoder_image(seed: int, b: int, h: int, w: int):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    img = rng.random((b, 1, h, w), dtype=np.float32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for i in range(b):
+        for _ in range(25):   # blobs and edges so that the response is structured
+            cy, cx = rng.integers(0, h), rng.integers(0, w)
+            img[i, 0] += (rng.uniform(0.3, 1.0) * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / rng.uniform(4.0, 60.0))).astype(np.float32)
+    return np.clip(img, 0, 1.5).astype(np.float32)
+
+
+def load_reference_superpoint(sd, **conf):
+    """The reference SuperPoint CLASS itself (superpoint.py:98-232), unmodified: its module is executed with stand-ins for the
+    absent kornia import and the package's Extractor base (whose __init__ only merges the conf, utils.py:127-131), and
+    torch.hub.load_state_dict_from_url — the network download of ref :143-144 — returns the seeded state dict."""
+    from types import SimpleNamespace
+
+    class Extractor(torch.nn.Module):
+        def __init__(self, **c):
+            super().__init__()
+            self.conf = SimpleNamespace(**{**self.default_conf, **c})
+
+    stub = types.ModuleType("kornia"); color = types.ModuleType("kornia.color"); color.rgb_to_grayscale = None
+    pkg = types.ModuleType("lgref"); pkg.__path__ = []
+    utils = types.ModuleType("lgref.utils"); utils.Extractor = Extractor
+    saved = {k: sys.modules.get(k) for k in ("kornia", "kornia.color", "lgref", "lgref.utils")}
+    sys.modules.update({"kornia": stub, "kornia.color": color, "lgref": pkg, "lgref.utils": utils})
+    orig = torch.hub.load_state_dict_from_url
+    torch.hub.load_state_dict_from_url = lambda url, *a, **k: sd
+    try:
+        mod = types.ModuleType("lgref.superpoint"); mod.__package__ = "lgref"
+        exec(compile(REF.read_text(), str(REF), "exec"), mod.__dict__)
+        model = mod.SuperPoint(**conf).eval()
+    finally:
+        torch.hub.load_state_dict_from_url = orig
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return model
+
+
+def reference_encode(model, image: torch.Tensor):
+    """scores (before NMS) and the raw convDb map of the reference forward: the statements of superpoint.py:159-184 / :213-214
+    executed on the reference module's own layers."""
+    x = model.relu(model.conv1a(image)); x = model.relu(model.conv1b(x)); x = model.pool(x)
+    x = model.relu(model.conv2a(x)); x = model.relu(model.conv2b(x)); x = model.pool(x)
+    x = model.relu(model.conv3a(x)); x = model.relu(model.conv3b(x)); x = model.pool(x)
+    x = model.relu(model.conv4a(x)); x = model.relu(model.conv4b(x))
+    sc = model.convPb(model.relu(model.convPa(x)))
+    sc = torch.nn.functional.softmax(sc, 1)[:, :-1]
+    b, _, h, w = sc.shape
+    sc = sc.permute(0, 2, 3, 1).reshape(b, h, w, 8, 8).permute(0, 1, 3, 2, 4).reshape(b, h * 8, w * 8)
+    return sc, model.convDb(model.relu(model.convDa(x)))
+
+
 def main():
     ref = load_reference_functions()
+    out_dir0 = ROOT / "tests" / "golden"
+    for name, (wseed, iseed, b, h, w, topk) in ENCODE_CASES.items():
+        sd = encoder_state_dict(wseed)
+        model = load_reference_superpoint(sd, max_num_keypoints=topk)
+        img = torch.from_numpy(encoder_image(iseed, b, h, w))
+        with torch.no_grad():
+            sc, dense = reference_encode(model, img)
+            arrays = {"case": np.array([wseed, iseed, b, h, w, -1 if topk is None else topk]), "scores": sc.numpy().astype(np.float32),
+                      "dense_digest": np.array([float(dense.double().abs().mean()), float(dense.double().pow(2).mean())]),
+                      "dense_sample": dense[:, ::16, ::3, ::5].numpy().astype(np.float32)}
+            if topk is not None or b == 1:   # the reference's forward stacks per-image results: equal counts needed
+                out = model({"image": img})
+                arrays.update(keypoints=out["keypoints"].numpy(), keypoint_scores=out["keypoint_scores"].numpy(), descriptors=out["descriptors"].numpy())
+        np.savez_compressed(out_dir0 / f"{name}.npz", **arrays)
+        print(name, "scores", tuple(sc.shape), "max", float(sc.max()), "keypoints", None if "keypoints" not in arrays else arrays["keypoints"].shape)
     out_dir = ROOT / "tests" / "golden"
     for name, (seed, b, h, w, topk) in DETECT_CASES.items():
         smap = score_map(seed, b, h, w)

@@ -145,10 +145,6 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
             bv[j] = a.bias[col0 + lr];
         }
     }
-#ifdef LG_PROJ_EPI_DRAIN
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
     for (int j = 0; j < NTP; ++j) {
         constexpr int dummy = 0; (void)dummy;

@@ -309,6 +309,16 @@ def main():
         for _ in range(args.warmup):
             out = step()
     drain()
+
+    def mfma_clock():
+        import ctypes as C
+        from lightglue_amd import _cabi
+        v = C.c_double(0.0)
+        with torch.cuda.device(dev):
+            _cabi.check(_cabi.load().lg_debug_mfma_clock_mhz(C.byref(v), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return round(v.value, 1)
+
+    clock_before = mfma_clock()
     model.profile(True, dev, only=dom_class)
     barrier()
     t0 = time.perf_counter()
@@ -382,6 +392,9 @@ def main():
                                           "avg_launch_ms come from events inside the timed region") if warm_prof else "HIP events inside the timed region",
             "gpu_ms_per_step_sum": round(sum(kernel_ms.values()), 3),
             "algorithmic_tflops": value * flops_per_pair(n, m) / 1e12,
+            # shader clock this box sustains under a matrix-core-dense load, measured right before the timed region: the pool's
+            # boxes differ by up to ~20 % for one binary, and most of it is this clock
+            "effective_mfma_clock_mhz": clock_before,
             "matches_per_pair": float(np.mean([(o > -1).sum().item() for o in out["matches0"]])) if "matches0" in out else None,
         }
         # match-index parity of the batch that was just timed (rank 0's pairs): against the reference's own fixture for the

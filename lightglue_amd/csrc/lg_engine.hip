@@ -611,6 +611,51 @@ int lg_sp_detect(const float* scores, int32_t batch, int32_t h, int32_t w, int32
     return LG_OK;
 }
 
+namespace {
+// matrix-core-dense spin: every wave issues independent 16x16x32 bf16 MFMAs; block 0 / wave 0 reports its shader-clock span
+__global__ __launch_bounds__(512) void mfma_clock_kernel(long long* cycles, int iters) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    bf16x8_t x, y;
+    for (int i = 0; i < 8; ++i) { x[i] = (__bf16)(0.001f * (threadIdx.x & 63) + i); y[i] = (__bf16)(1.0f + 0.01f * i); }
+    f32x4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("" : "+v"(x), "+v"(y));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, acc[i], 0, 0, 0);
+    }
+    const long long t1 = clock64();
+    float sacc = 0.f;
+    for (int i = 0; i < 8; ++i) sacc += acc[i][0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { cycles[0] = t1 - t0; cycles[1] = sacc == 12345.f; }
+}
+}  // namespace
+
+/* Effective shader clock (MHz) while every SIMD issues MFMAs back to back for ~1-2 ms: clock64() span of one wave / HIP-event
+ * duration of the launch.  The pool's MI355X boxes sustain different clocks under matrix load (power management), which is what
+ * separates "fast" and "slow" boxes for the same binary; bench.py reports it next to the throughput. */
+int lg_debug_mfma_clock_mhz(double* mhz, void* hip_stream) {
+    if (!mhz) return fail(LG_ERR_INVALID, "null pointer");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    long long* d = nullptr;
+    HIPCHK(hipMalloc(&d, 16));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    const int iters = 20000;
+    hipLaunchKernelGGL(mfma_clock_kernel, dim3(256), dim3(512), 0, s, d, iters / 10);   // warm-up / clock ramp
+    HIPCHK(hipEventRecord(a, s));
+    hipLaunchKernelGGL(mfma_clock_kernel, dim3(256), dim3(512), 0, s, d, iters);
+    HIPCHK(hipEventRecord(b, s));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0.f; long long h[2] = {0, 0};
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    HIPCHK(hipMemcpy(h, d, 16, hipMemcpyDeviceToHost));
+    (void)hipFree(d); (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *mhz = ms > 0.f ? (double)h[0] / (ms * 1e3) : 0.0;
+    return LG_OK;
+}
+
 int lg_engine_debug_caps(lg_engine* e, int32_t* cap0, int32_t* cap1) {
     if (!e || !cap0 || !cap1) return fail(LG_ERR_INVALID, "null argument");
     *cap0 = e->cur_cap0; *cap1 = e->cur_cap1;

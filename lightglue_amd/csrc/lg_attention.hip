@@ -306,6 +306,242 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the 16-bit, 32-rows-per-wave kernel (the default operating point).  Same mathematics, same
+// operand layouts, same instruction order inside a tile, so its output is bit-identical to attn_kernel<Tag, 2>.
+// What changes is how a K / V^T tile reaches LDS and how often the workgroup synchronises:
+//   * `global_load_lds_dwordx4`: each wave moves 2 + 2 pieces of 1 KB (8 rows x 128 B) per tile straight from L2 into
+//     LDS.  The DMA writes lane l's 16 bytes at piece base + 16 l, so the bank swizzle is applied on the SOURCE side:
+//     lane l fetches the logical slot that belongs at physical slot l & 7 of row l >> 3.
+//   * two tile buffers (32 KB per workgroup, 4 workgroups per CU) and ONE barrier per tile: "my pieces of tile t have
+//     landed" (vmcnt) + barrier = tile t complete AND every wave done with tile t - 1, whose buffer then takes tile t + 1
+//     while tile t is being multiplied.
+//   * no staging registers -> 128 VGPRs -> 4 waves per SIMD (was 3): at N = M = 1024, B = 32 the 2048 workgroups of a
+//     launch are exactly 2 full rounds of the chip instead of 2.67;
+//   * LDS fragment addresses as two per-lane bases + immediates (the swizzle depends on the lane only);
+//   * wave priority by progress (see the tile loop).
+// A partial last tile is fixed up in LDS (V^T columns past the live length are zeroed: 0 x stale-NaN must not happen;
+// K rows past it need nothing, their scores are overwritten with -inf).
+template <class Tag>
+__global__ __launch_bounds__(ATHREADS, 4) void attn_dma_kernel(AttnArgs a) {
+    constexpr int QT = 2, ABM = 128, ROWB = 128, TILEB = 64 * ROWB, BUFB = 2 * TILEB;
+    typedef typename Tag::elem T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int ntile = gridDim.x >> 2;
+    const int v = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = v / ntile;
+    const TileLoc t = locate_tile(a.rs, v - head * ntile, ABM);
+    const int qlen = a.rs.len[t.seg];
+    if (t.r0 >= qlen) return;
+    if (a.rs.active && !a.rs.active[t.pair]) return;
+    const int kvseg = a.cross ? (t.seg ^ 1) : t.seg;
+    const int kvlen = a.rs.len[kvseg];
+    const long long kvbase = seg_row_base(a.rs, kvseg);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, g = lane >> 4;
+    const long long R = a.R;
+    const T* Q = static_cast<const T*>(a.q);
+    const T* Kp = static_cast<const T*>(a.cross ? a.q : a.k);
+    const T* Vt = static_cast<const T*>(a.vt);
+
+    if (kvlen == 0) {  // ref :114-115: empty key set -> zeros
+        for (int i = tid; i < ABM * 16; i += ATHREADS) {
+            const int row = i >> 4, c4 = i & 15;
+            if (t.r0 + row < qlen) *reinterpret_cast<f32x4*>(a.ctx + (t.grow0 + row) * 256LL + head * 64 + c4 * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
+
+    // DMA source offsets (elements), per lane: piece p = 2 * wave + i covers tile rows 8p .. 8p + 7
+    const int prow = lane >> 3, pslot = lane & 7;
+    int koff[2], voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (2 * wave + i) * 8 + prow;
+        koff[i] = row * 64 + ((pslot ^ (((row >> 1) & 1) | (((row >> 3) & 3) << 1))) << 3);          // inverse of k_off<128>
+        voff[i] = (pslot ^ ((row >> 1) & 7)) << 3;                                                      // inverse of lds_off<128>; + row * R below
+    }
+    const T* kseg = Kp + ((long long)head * R + kvbase) * 64;
+    const T* vrow[2] = {Vt + ((long long)head * 64 + (2 * wave) * 8 + prow) * R + kvbase + voff[0],
+                        Vt + ((long long)head * 64 + (2 * wave + 1) * 8 + prow) * R + kvbase + voff[1]};
+    auto dma_tile = [&](int buf, int kv0) {
+        char* bK = smem + buf * BUFB; char* bV = bK + TILEB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kseg + (long long)kv0 * 64 + koff[i]),
+                                             (__attribute__((address_space(3))) void*)(bK + (2 * wave + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vrow[i] + kv0),
+                                             (__attribute__((address_space(3))) void*)(bV + (2 * wave + i) * 1024), 16, 0, 0);
+        }
+    };
+    dma_tile(0, 0);
+
+    // LDS fragment offsets: the swizzle terms depend on the lane only (K: row bits 1, 3, 4; V^T: row bits 1..3), so tile
+    // (kt, dt) steps are immediate offsets and a k-chunk step (slot bit 2, inside the XOR) needs a second base register
+    int kfo[2], vfo[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        kfo[c] = k_off<ROWB>(8 * (lr >> 2) + (lr & 3), c * 4 + g);
+        vfo[c] = TILEB + lds_off<ROWB>(lr, 4 * c + g);
+    }
+    u32x4 qf[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const long long grow = (long long)t.grow0 + wave * 32 + qt * 16 + lr;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) qf[qt][c] = *reinterpret_cast<const u32x4*>(Q + ((long long)head * R + grow) * 64 + c * 32 + g * 8);
+    }
+    f32x4 o[4][QT];
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        m_run[qt] = -INFINITY; l_run[qt] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int ntiles = (kvlen + ABK - 1) / ABK;
+#ifdef LG_ATTN_TIMING
+    long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+#endif
+#ifdef LG_ATTN_WALL    // experiment: workgroup life span on the 100 MHz wall clock + where it ran (no per-phase stamps)
+    const long long wall0 = wall_clock64(), cyc0 = clock64();
+#endif
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int kv0 = tile * ABK;
+        const char* bK = smem + (tile & 1) * BUFB; const char* bV = bK + TILEB;
+        // The SIMD arbiter issues oldest-wave-first, so of the 4 waves sharing a SIMD the first one ran at nearly solo speed
+        // and the last one at a third of it: workgroup lives spread 20 ... 57 us, the second round started ragged and the
+        // kernel ended with a 25 us ramp-down at <= 75 % occupancy (tools/attn_wall.py).  Priority by PROGRESS (the wave
+        // that is furthest behind issues first) makes the co-resident waves finish together: two sharp rounds, -3.5 %.
+        if ((tile & 3) == 0) {
+            const int q = (tile * 4) / ntiles;
+            if (q == 0) __builtin_amdgcn_s_setprio(3); else if (q == 1) __builtin_amdgcn_s_setprio(2); else if (q == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of this tile (and, first time round, my Q fragments)
+        __syncthreads();
+        ATT_TICK(0);
+        if (kv0 + ABK > kvlen) {                            // workgroup-uniform: zero the dead key columns of V^T
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = tid + ATHREADS * i, row = c >> 3, slot = c & 7;
+                u32x4* p = reinterpret_cast<u32x4*>(const_cast<char*>(bV) + lds_off<ROWB>(row, slot));
+                *p = mask_tail<Tag>(*p, kvlen - (kv0 + slot * 8));
+            }
+            __syncthreads();
+        }
+        if (tile + 1 < ntiles) dma_tile((tile + 1) & 1, kv0 + ABK);
+        __builtin_amdgcn_sched_barrier(0);
+        ATT_TICK(1);
+
+        f32x4 s[4][QT];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(bK + kfo[c] + (32 * (kt >> 1) + 4 * (kt & 1)) * ROWB);   // key row 32 (kt >> 1) + 8 (lr >> 2) + 4 (kt & 1) + (lr & 3)
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(s[kt][qt], kf, qf[qt][c]);
+            }
+        }
+        ATT_TICK(2);
+        if (kv0 + ABK > kvlen) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kv0 + 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r >= kvlen) s[kt][qt][r] = -INFINITY;
+        }
+        float m_new[QT];
+        bool grew = false;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const float t0 = vmax3(s[0][qt][0], s[0][qt][1], s[0][qt][2]), t1 = vmax3(s[0][qt][3], s[1][qt][0], s[1][qt][1]);
+            const float t2 = vmax3(s[1][qt][2], s[1][qt][3], s[2][qt][0]), t3 = vmax3(s[2][qt][1], s[2][qt][2], s[2][qt][3]);
+            const float t4 = vmax3(s[3][qt][0], s[3][qt][1], s[3][qt][2]);
+            float mx = vmax2(vmax3(t0, t1, t2), vmax3(t3, t4, s[3][qt][3]));
+            mx = xor32_max(xor16_max(mx));
+            m_new[qt] = vmax2(m_run[qt], mx * a.scale_log2e);
+            grew = grew || (m_new[qt] > m_run[qt] + 8.f);
+        }
+        if (__any(grew)) {   // deferred rescale, see attn_kernel
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new[qt]);
+                l_run[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt][qt] *= alpha;
+                m_run[qt] = m_new[qt];
+            }
+        }
+        ATT_TICK(3);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const float sc = a.scale_log2e, nm = -m_run[qt];
+            float rs0 = 0.f, rs1 = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][0], sc, nm)), p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][1], sc, nm));
+                const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][2], sc, nm)), p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][3], sc, nm));
+                s[kt][qt][0] = p0; s[kt][qt][1] = p1; s[kt][qt][2] = p2; s[kt][qt][3] = p3;
+                rs0 += p0 + p2; rs1 += p1 + p3;
+            }
+            l_run[qt] += rs0 + rs1;
+        }
+        ATT_TICK(4);
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {
+            u32x4 pp[QT];
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) pp[qt] = pack8<Tag>(s[2 * tp][qt], s[2 * tp + 1][qt]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const u32x4 vf = *reinterpret_cast<const u32x4*>(bK + vfo[tp] + dt * 16 * ROWB);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(o[dt][qt], vf, pp[qt]);
+            }
+        }
+        ATT_TICK(5);
+    }
+#ifdef LG_ATTN_TIMING
+    if (a.dbg && lane == 0) {
+        long long* d = a.dbg + ((long long)blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 6; ++i) d[i] = tacc[i];
+        d[6] = ntiles; d[7] = 1;
+    }
+#endif
+#ifdef LG_ATTN_WALL
+    if (a.dbg && lane == 0) {
+        long long* d = a.dbg + ((long long)blockIdx.x * 4 + wave) * 8;
+        d[0] = wall0; d[1] = wall_clock64(); d[2] = clock64() - cyc0; d[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4); d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 20); d[6] = ntiles; d[7] = 1;
+    }
+#endif
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float l = l_run[qt];
+        l = xor32_sum(xor16_sum(l));
+        const float inv = 1.f / l;
+        const int qrow = t.r0 + wave * 32 + qt * 16 + lr;
+        if (qrow < qlen) {
+            float* dst = a.ctx + (t.grow0 + wave * 32 + qt * 16 + lr) * 256LL + head * 64 + g * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(dst + dt * 16) = o[dt][qt] * inv;
+        }
+    }
+}
+
+template <class Tag> static hipError_t launch_attn_dma(const AttnArgs& a, hipStream_t s) {
+    const int tiles = a.rs.B * (a.rs.cap0 + a.rs.cap1) / 128;
+    hipLaunchKernelGGL((attn_dma_kernel<Tag>), dim3(tiles * 4), dim3(ATHREADS), 2 * 2 * 64 * 128, s, a);
+    return hipGetLastError();
+}
+
 template <class Tag, int QT> static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t s) {
     constexpr int ABM = 64 * QT;
     const int tiles = QT <= 2 ? a.rs.B * (a.rs.cap0 + a.rs.cap1) / ABM : a.rs.B * ((a.rs.cap0 + ABM - 1) / ABM + (a.rs.cap1 + ABM - 1) / ABM);
@@ -321,8 +557,8 @@ hipError_t launch_attention(int attn_prec, const AttnArgs& a, hipStream_t s) {
     const int rpw = a.rows_per_wave;
     switch (attn_prec) {
         case PREC_F32: return launch_attn_t<TagF32, 2>(a, s);
-        case PREC_BF16: return rpw == 64 ? launch_attn_t<TagBF16, 4>(a, s) : rpw == 16 ? launch_attn_t<TagBF16, 1>(a, s) : launch_attn_t<TagBF16, 2>(a, s);
-        case PREC_F16: return rpw == 64 ? launch_attn_t<TagF16, 4>(a, s) : rpw == 16 ? launch_attn_t<TagF16, 1>(a, s) : launch_attn_t<TagF16, 2>(a, s);
+        case PREC_BF16: if (a.dma && rpw == 32) return launch_attn_dma<TagBF16>(a, s); return rpw == 64 ? launch_attn_t<TagBF16, 4>(a, s) : rpw == 16 ? launch_attn_t<TagBF16, 1>(a, s) : launch_attn_t<TagBF16, 2>(a, s);
+        case PREC_F16: if (a.dma && rpw == 32) return launch_attn_dma<TagF16>(a, s); return rpw == 64 ? launch_attn_t<TagF16, 4>(a, s) : rpw == 16 ? launch_attn_t<TagF16, 1>(a, s) : launch_attn_t<TagF16, 2>(a, s);
     }
     return hipErrorInvalidValue;
 }

@@ -105,6 +105,7 @@ struct lg_engine {
     size_t tail_cat_layer_bytes = 0, tail_2_layer_bytes = 0;
     char *w_sqkv_p = nullptr, *w_cqkv_p = nullptr;   // fragment-packed projection weights (lg_proj.hip)
     size_t sqkv_layer_bytes = 0, cqkv_layer_bytes = 0;
+    bool attn_dma = true;   // option "attn_dma": LDS-DMA attention kernel (16-bit operands, 32 rows per wave)
     int attn_rows = 32;   // query rows per attention wave (32 | 64), option "attn_rows" / env LG_ATTN_ROWS
     int fused_tail = 1, fused_proj = 1, fused_next = 1, tail_variant = 0;   // tail_variant != 0: experiment builds only (lg_tail4.hip)
     int tail_timing = 0; long long* TAILDBG = nullptr;
@@ -532,6 +533,7 @@ int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
     if (std::strcmp(key, "tail_rows") == 0) { if (value != 0 && value != 64 && value != 128) return fail(LG_ERR_INVALID, "tail_rows must be 0, 64 or 128"); e->tail_rows = value; return LG_OK; }
 #endif
     if (std::strcmp(key, "fused_next") == 0) { e->fused_next = value != 0; return LG_OK; }
+    if (std::strcmp(key, "attn_dma") == 0) { e->attn_dma = value != 0; return LG_OK; }
     if (std::strcmp(key, "attn_rows") == 0) { if (value != 16 && value != 32 && value != 64) return fail(LG_ERR_INVALID, "attn_rows must be 16, 32 or 64"); e->attn_rows = value; return LG_OK; }
     if (std::strcmp(key, "profile_only") == 0) { e->prof_only = value; return LG_OK; }   // kernel class index, -1 = all classes
     if (std::strcmp(key, "tail_timing") == 0) { e->tail_timing = value; return LG_OK; }   // 1: tail kernel, 2: self projection, 3: self attention (LG_ATTN_TIMING builds)
@@ -783,7 +785,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 AttnArgs at{};
                 at.rs = rs_act; at.q = e->Q; at.k = e->K; at.vt = e->VT; at.ctx = e->CTX; at.R = R; at.cross = blk; at.scale_log2e = scale_log2e;
                 at.dbg = (e->tail_timing == 3 && blk == 0) ? e->TAILDBG : nullptr;
-                at.rows_per_wave = e->attn_rows;
+                at.rows_per_wave = e->attn_rows; at.dma = e->attn_dma ? 1 : 0;
                 TRY(prof_begin(e, blk == 0 ? PC_ATTN_SELF : PC_ATTN_CROSS, s));
                 HIPCHK(launch_attention(ap, at, s));
                 TRY(prof_end(e, s));

@@ -87,6 +87,7 @@ struct AttnArgs {
     float scale_log2e;
     long long* dbg;   // profiling builds (-DLG_ATTN_TIMING) only: [blocks][4 waves][8] phase clock sums
     int rows_per_wave;   // 32 or 64 query rows per wave (see launch_attention)
+    int dma;             // 16-bit, 32 rows per wave: the LDS-DMA kernel (attn_dma_kernel)
 };
 hipError_t launch_attention(int attn_prec, const AttnArgs& a, hipStream_t s);
 

@@ -401,6 +401,31 @@ def test_attention_rows_per_wave_variants_are_equivalent(precision):
         model.set_option("attn_rows", 32)
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_attention_lds_dma_kernel_is_bit_identical(precision):
+    """The default attention kernel brings K / V^T tiles into LDS by DMA (option attn_dma, default on; two buffers, one
+    barrier per tile); with the option off the register-staged kernel runs.  Same arithmetic in the same order, so all outputs
+    must be BIT-identical: key counts that end mid-tile, cross attention between unequal sets, one-tile key sets, adaptive
+    runs with compaction — and a workspace that a previous call left full of NaN (a partial tile's dead V^T columns are
+    fixed up in LDS, they must never reach the MFMA)."""
+    require_gpu()
+    for (n0, n1, recipe, kw) in ((300, 333, "A", dict(depth_confidence=-1, width_confidence=-1)), (130, 520, "B", dict(pruning_min_kpts=64)),
+                                 (1024, 1024, "A", dict(depth_confidence=-1, width_confidence=-1)), (40, 700, "C", dict())):
+        sd = synth.make_state_dict(0, recipe=recipe)
+        model = gpu_util.make_model(sd, precision, **kw)
+        poison = gpu_util.to_torch(synth.make_batch(5, 2, max(n0, 384), max(n1, 384)))
+        poison["image0"]["descriptors"][:] = float("nan"); poison["image1"]["descriptors"][:] = float("nan")
+        model(poison)                                      # every row of Q / K / V^T now holds NaN
+        data = gpu_util.to_torch(synth.make_batch(23, 2, n0, n1))
+        dma = model(data)
+        model.set_option("attn_dma", 0)
+        model(poison)
+        staged = model(data)
+        for key in ("matches0", "matches1", "matching_scores0", "matching_scores1", "prune0", "prune1"):
+            assert torch.equal(dma[key], staged[key]), (n0, n1, key)
+        assert torch.isfinite(dma["matching_scores0"]).all() and (dma["matches0"] > -1).any(), (n0, n1)
+
+
 def test_product_library_has_no_experiment_variants():
     """The streaming tail variants and the LG_* environment switches exist in experiment builds only (-DLG_EXPERIMENTS)."""
     require_gpu()

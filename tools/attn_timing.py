@@ -16,9 +16,12 @@ model(data); model.set_option("tail_timing", 3); model(data); torch.cuda.synchro
 d = model.debug_read("TAILDBG", np.int64).reshape(-1, 4, 8)
 d = d[d[:, 0, 7] == 1]
 tiles = d[:, :, 6].astype(np.float64)
+dma = (len(sys.argv) <= 2 or sys.argv[2] != "staged")
+if not dma: model.set_option("attn_dma", 0); model(data); torch.cuda.synchronize(); d = model.debug_read("TAILDBG", np.int64).reshape(-1, 4, 8); d = d[d[:, 0, 7] == 1]; tiles = d[:, :, 6].astype(np.float64)
 names = ["barrier 1 (wait for all waves' PV)", "store tile + barrier 2", "next-tile loads + K frags + QK MFMA issue",
-         "QK drain + max + shfl + any", "rescale + exp", "pack + V frags + PV MFMA issue"]
-print(prec, "s_memtime ticks PER TILE per wave (100 MHz ticks; x ~21-24 shader cycles); median / p10 / p90 over", d.shape[0], "blocks x 4 waves")
+         "QK drain + max + shfl + any", "rescale + exp", "pack + V frags + PV MFMA issue"] if not dma else \
+        ["vmcnt(0) + barrier", "issue next tile's DMA", "K frags + QK MFMA issue", "QK drain + max + swaps + rescale", "exp", "pack + V frags + PV MFMA issue"]
+print(prec, "dma" if dma else "staged", "s_memtime ticks PER TILE per wave; median / p10 / p90 over", d.shape[0], "blocks x 4 waves")
 tot = 0
 for i, n in enumerate(names):
     v = (d[:, :, i] / tiles).ravel()

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8 + slot] = clock64();
     };
     stamp(0);
+    if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8 + 6] = wall_clock64();   // 100 MHz wall clock: occupancy timeline (tools/tail_wall.py)
     // guide T5, static form: the second-dispatched half of an 8-wave workgroup loses issue arbitration to the older half on
     // every phase; one priority bump for it, no per-cluster flips (measured: tail -0.2 ... -1.3 %)
     if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
@@ -379,6 +380,8 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     }
     stamp(5);
     if constexpr (NEXT != 0) proj_compute<(PREC == PREC_BF16X3 ? PREC_QKV_F16W2 : PREC), TA, NEXT == 1 ? 3 : 2, 2, G_PLANE>(a.next, t, smem, 8);
+    if (a.dbg && lane == 0)   // wall clock at the end + where the workgroup ran (HW_ID, XCC_ID)
+        a.dbg[((long long)blockIdx.x * 8 + w) * 8 + 7] = (wall_clock64() & ((1LL << 44) - 1)) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFF00) << 40) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 44);
 }
 
 template <int PREC, int NEXT, class TA> static hipError_t launch_tail_t(const TailArgs& a, hipStream_t s) {

@@ -21,6 +21,7 @@ print("workgroups", len(d), " kernel span (first start -> last end) %.1f us" % (
 life = (t1 - t0) / 100.0
 print("workgroup life us: median %.1f  p10 %.1f  p90 %.1f  max %.1f;  shader cycles per life: median %.0f -> clock %.0f MHz" %
       (np.median(life), np.percentile(life, 10), np.percentile(life, 90), life.max(), np.median(cyc), np.median(cyc / life)))
+assert 0 < t1.max() - base < 10_000_000
 ts = np.arange(0, (t1.max() - base), 200)   # every 2 us
 live = [(int(((t0 - base) <= t) & ((t1 - base) > t)).sum()) if False else int((((t0 - base) <= t) & ((t1 - base) > t)).sum()) for t in ts]
 print("live workgroups every 2 us:", live)

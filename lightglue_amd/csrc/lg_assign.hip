@@ -66,13 +66,16 @@ __global__ __launch_bounds__(256) void lse_sweep_kernel(AssignArgs a) {
             nxt = *reinterpret_cast<const f32x4*>(col + (long long)min(r + 1, rows - 1) * a.rs.cap1);   // next row in flight
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (!act || c + i >= len1) v[i] = -INFINITY;
-            const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-            float m = m4, sum = act ? (fexp(v[0] - m4) + fexp(v[1] - m4)) + (fexp(v[2] - m4) + fexp(v[3] - m4)) : 0.f;
+            // row statistic: the WAVE's maximum first (12 DPP / permlane ops), then every lane exponentiates against it and the
+            // sums are added across the wave — 4 exponentials per lane and row (the pairwise log-sum-exp merge tree cost 10)
+            const float m = wave_allmax(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+            float sum = 0.f;
+            if (m != -INFINITY) sum = (fexp(v[0] - m) + fexp(v[1] - m)) + (fexp(v[2] - m) + fexp(v[3] - m));   // wave-uniform branch; dead lanes add exp(-inf) = 0
             if (act) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) lse_merge1(cm[i], cs[i], v[i], v[i] == -INFINITY ? 0.f : 1.f);
             }
-            wave_allreduce2(m, sum, [](float& m0, float& s0, float m2, float s2) { lse_merge1(m0, s0, m2, s2); });
+            sum = wave_allsum(sum);
             if (lane == 0) {
                 if (c0 == 0) { shm[wave][r] = m; shs[wave][r] = sum; }
                 else { float mo = shm[wave][r], so = shs[wave][r]; lse_merge1(mo, so, m, sum); shm[wave][r] = mo; shs[wave][r] = so; }
@@ -91,25 +94,28 @@ __global__ __launch_bounds__(256) void lse_sweep_kernel(AssignArgs a) {
     }
 }
 
-// ---- merge the column partials: lse_c[b] over the live row tiles.  grid (cap1/256, B)
+// ---- merge the column partials: lse_c[b] over the live row tiles.  grid (cap1/64, B): a wave = 64 consecutive columns of
+// every 4th row tile, so that a thread has <= 8 independent (max, sum) loads in flight per round and the 4 partial results
+// meet in LDS.  (One thread per column walking all tiles was latency-bound: 19 us for 8 MB at cfg #2.)
 __global__ __launch_bounds__(256) void col_lse_merge_kernel(AssignArgs a) {
-    const int pair = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    const int pair = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
     const int len0 = a.rs.len[2 * pair], len1 = a.rs.len[2 * pair + 1];
-    if (c >= len1) return;
+    if (blockIdx.x * 64 >= len1) return;                  // workgroup-uniform
     const int ntiles = a.rs.cap0 / ART, live = (len0 + ART - 1) / ART;
-    const float* pm = a.cpm + (long long)pair * ntiles * a.rs.cap1 + c;
-    const float* ps = a.cps + (long long)pair * ntiles * a.rs.cap1 + c;
-    // two independent passes (max, then scaled sum) instead of a serial chain of dependent merges: the loads of a pass
-    // are all in flight together (the chained form was latency-bound: 12 us for 8 MB)
+    const int cc = min(c, a.rs.cap1 - 1);                 // (cap1 is a multiple of 128: always in range; keeps the loads unconditional)
+    const float* pm = a.cpm + (long long)pair * ntiles * a.rs.cap1 + cc;
+    const float* ps = a.cps + (long long)pair * ntiles * a.rs.cap1 + cc;
     float m = -INFINITY, s = 0.f;
 #pragma unroll 8
-    for (int t = 0; t < live; ++t) m = fmaxf(m, pm[(long long)t * a.rs.cap1]);
-#pragma unroll 8
-    for (int t = 0; t < live; ++t) {
-        const float pmt = pm[(long long)t * a.rs.cap1];
-        s += pmt == -INFINITY ? 0.f : ps[(long long)t * a.rs.cap1] * fexp(pmt - m);
+    for (int t = wave; t < live; t += 4) lse_merge1(m, s, pm[(long long)t * a.rs.cap1], ps[(long long)t * a.rs.cap1]);
+    __shared__ float shm[4][64], shs[4][64];
+    shm[wave][lane] = m; shs[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < len1) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) lse_merge1(m, s, shm[w][lane], shs[w][lane]);
+        a.lse_c[(long long)pair * a.rs.cap1 + c] = m + logf(s);
     }
-    a.lse_c[(long long)pair * a.rs.cap1 + c] = m + logf(s);
 }
 
 __device__ __forceinline__ float score_of(float sim, float lr, float lc, float cert) {
@@ -155,13 +161,13 @@ __global__ __launch_bounds__(256) void argmax_sweep_kernel(AssignArgs a) {
                     if (sc > cb[i]) { cb[i] = sc; ci[i] = r0 + r; }           // ascending rows: first index wins
                 }
             }
-            float bif = __int_as_float(bi);   // the index travels as a bit pattern through the DPP moves
-            wave_allreduce2(best, bif, [](float& b0, float& i0, float b2, float i2) {
-                const int x = __float_as_int(i0), y = __float_as_int(i2);
-                if (b2 > b0 || (b2 == b0 && y < x)) { b0 = b2; i0 = i2; }
-            });
+            // wave maximum by value only (12 ops); its first index is the index held by the LOWEST lane that has it (lanes hold
+            // ascending columns): ballot + s_ff1 + v_readlane instead of carrying the index through every reduction step
+            const float wbest = wave_allmax(best);
+            const unsigned long long owners = __ballot(best == wbest);    // never empty: all lanes hold -inf when the row has no finite score
+            const int wbi = __builtin_amdgcn_readlane(bi, (int)__builtin_ctzll(owners));
             if (lane == 0) {
-                if (c0 == 0 || best > shb[wave][r]) { shb[wave][r] = best; shi[wave][r] = __float_as_int(bif); }   // later passes = higher columns: strict >
+                if (c0 == 0 || wbest > shb[wave][r]) { shb[wave][r] = wbest; shi[wave][r] = wbi; }   // later passes = higher columns: strict >
             }
         }
         if (act) {
@@ -180,27 +186,52 @@ __global__ __launch_bounds__(256) void argmax_sweep_kernel(AssignArgs a) {
     }
 }
 
-// ---- merge the column argmax partials (ascending row tiles, strict '>': first index).  grid (cap1/256, B)
+// ---- merge the column argmax partials (first index = lowest row wins).  Same decomposition as col_lse_merge_kernel.
 __global__ __launch_bounds__(256) void col_argmax_merge_kernel(AssignArgs a) {
-    const int pair = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    const int pair = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
     const int len0 = a.rs.len[2 * pair], len1 = a.rs.len[2 * pair + 1];
-    if (c >= len1) return;
+    if (blockIdx.x * 64 >= len1) return;
     const int ntiles = a.rs.cap0 / ART, live = (len0 + ART - 1) / ART;
-    const float* pv = a.cbv + (long long)pair * ntiles * a.rs.cap1 + c;
-    const int* pi = a.cbi + (long long)pair * ntiles * a.rs.cap1 + c;
+    const int cc = min(c, a.rs.cap1 - 1);
+    const float* pv = a.cbv + (long long)pair * ntiles * a.rs.cap1 + cc;
+    const int* pi = a.cbi + (long long)pair * ntiles * a.rs.cap1 + cc;
     float best = -INFINITY; int bi = 0;
 #pragma unroll 8
-    for (int t = 0; t < live; ++t) {   // (both loads unconditional: 8 tiles' worth stay in flight)
+    for (int t = wave; t < live; t += 4) {   // ascending rows within a wave: strict '>'
         const float v = pv[(long long)t * a.rs.cap1];
         const int vi = pi[(long long)t * a.rs.cap1];
         if (v > best) { best = v; bi = vi; }
     }
-    a.max1[(long long)pair * a.rs.cap1 + c] = best; a.arg1[(long long)pair * a.rs.cap1 + c] = bi;
+    __shared__ float shb[4][64]; __shared__ int shi[4][64];
+    shb[wave][lane] = best; shi[wave][lane] = bi;
+    __syncthreads();
+    if (wave == 0 && c < len1) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {        // the waves interleave row tiles: ties go to the lower row
+            const float v = shb[w][lane]; const int vi = shi[w][lane];
+            if (v > best || (v == best && v != -INFINITY && vi < bi)) { best = v; bi = vi; }
+        }
+        a.max1[(long long)pair * a.rs.cap1 + c] = best; a.arg1[(long long)pair * a.rs.cap1 + c] = bi;
+    }
 }
 
-// ---- final: one workgroup per pair
+// ---- final: grid (ceil(max(cap0, cap1) / 256), B); workgroup j owns rows [256 j, 256 j + 256) of both images.
+// The compact match list is sorted by the image-0 row, so a workgroup needs the number of valid rows below its own: it
+// recomputes their validity (3 dependent 4-byte loads per row; at most cap0 / 256 - 1 extra rounds) instead of waiting for
+// its predecessors — no inter-workgroup dependency, and one workgroup per pair was 10 us on a 256-CU chip.
+struct Row0 { bool valid; int j; float e; };
+__device__ __forceinline__ Row0 match_of_row0(const AssignArgs& a, const float* max0, const int* arg0, const int* arg1, int r, int len1) {
+    // a row whose scores are all NaN (NaN / Inf in the inputs) keeps the argmax sentinel: treat it as unmatched instead of
+    // indexing with it (the reference returns garbage there, but does not fault)
+    const int jraw = arg0[r];
+    const bool jok = (unsigned)jraw < (unsigned)len1;
+    const int j = jok ? jraw : 0;
+    const bool mutual0 = jok && arg1[j] == r;
+    const float e = mutual0 ? expf(max0[r]) : 0.f;
+    return {mutual0 && (e > a.filter_threshold), j, e};
+}
 __global__ __launch_bounds__(256) void finalize_kernel(AssignArgs a) {
-    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pair = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int len0 = a.rs.len[2 * pair], len1 = a.rs.len[2 * pair + 1];
     const int base0 = seg_row_base(a.rs, 2 * pair), base1 = seg_row_base(a.rs, 2 * pair + 1);
     const float* max0 = a.max0 + (long long)pair * a.rs.cap0;
@@ -208,53 +239,52 @@ __global__ __launch_bounds__(256) void finalize_kernel(AssignArgs a) {
     const int* arg1 = a.arg1 + (long long)pair * a.rs.cap1;
     int* m0 = a.m0 + (long long)pair * a.n0; float* s0 = a.s0 + (long long)pair * a.n0;
     int* m1 = a.m1 + (long long)pair * a.n1; float* s1 = a.s1 + (long long)pair * a.n1;
-    __shared__ int sh_cnt[4];
-    if (len0 == 0 || len1 == 0) { if (tid == 0) a.n_matches[pair] = 0; return; }
+    __shared__ int sh_cnt[4], sh_below[4];
+    if (len0 == 0 || len1 == 0) { if (blk == 0 && tid == 0) a.n_matches[pair] = 0; return; }
     // image 1 side (ref :309, :313, :315, :317)
-    for (int b = tid; b < len1; b += 256) {
-        const int i = arg1[b];
-        const bool mutual1 = arg0[i] == b;
-        const float e = expf(max0[i]);            // mutual1 implies mutual0(i), so mscores0[i] = exp(max0[i])
-        const bool valid1 = mutual1 && (e > a.filter_threshold);
-        const int ob = a.ind[base1 + b];
-        m1[ob] = valid1 ? a.ind[base0 + i] : -1;
-        s1[ob] = mutual1 ? e : 0.f;
+    {
+        const int b = blk * 256 + tid;
+        if (b < len1) {
+            const int i = arg1[b];
+            const bool mutual1 = arg0[i] == b;
+            const float e = expf(max0[i]);            // mutual1 implies mutual0(i), so mscores0[i] = exp(max0[i])
+            const bool valid1 = mutual1 && (e > a.filter_threshold);
+            const int ob = a.ind[base1 + b];
+            m1[ob] = valid1 ? a.ind[base0 + i] : -1;
+            s1[ob] = mutual1 ? e : 0.f;
+        }
     }
+    if (blk * 256 >= len0 && blk != (int)gridDim.x - 1) return;   // (the last workgroup reports the count)
     // image 0 side + compact list, ascending a (ref :308, :312, :314, :316, :595-602)
-    int running = 0;
-    int* ml = a.matches + (long long)pair * a.max_matches * 2;
-    float* msl = a.mscores + (long long)pair * a.max_matches;
-    for (int a0 = 0; a0 < len0; a0 += 256) {
-        const int r = a0 + tid;
-        bool valid0 = false; int oa = 0, ob = -1; float e = 0.f;
-        if (r < len0) {
-            // a row whose scores are all NaN (NaN / Inf in the inputs) keeps the argmax sentinel: treat it as unmatched
-            // instead of indexing with it (the reference returns garbage there, but does not fault)
-            const int jraw = arg0[r];
-            const bool jok = (unsigned)jraw < (unsigned)len1;
-            const int j = jok ? jraw : 0;
-            const bool mutual0 = jok && arg1[j] == r;
-            e = mutual0 ? expf(max0[r]) : 0.f;
-            valid0 = mutual0 && (e > a.filter_threshold);
-            oa = a.ind[base0 + r];
-            ob = valid0 ? a.ind[base1 + j] : -1;
-            m0[oa] = ob;
-            s0[oa] = e;
-        }
-        const unsigned long long bal = __ballot(valid0);
-        const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
-        __syncthreads();
-        if (lane == 0) sh_cnt[wave] = __popcll(bal);
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wave; ++w) woff += sh_cnt[w];
-        if (valid0) {
-            const int k = running + woff + prefix;
-            ml[2 * k] = oa; ml[2 * k + 1] = ob; msl[k] = e;
-        }
-        running += sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
+    int below = 0;                                                // valid rows of the workgroups before this one (wave-uniform partial)
+    for (int q = 0; q < blk; ++q) {
+        const int r = q * 256 + tid;
+        below += __popcll(__ballot(r < len0 && match_of_row0(a, max0, arg0, arg1, min(r, len0 - 1), len1).valid));
     }
-    if (tid == 0) a.n_matches[pair] = running;
+    const int r = blk * 256 + tid;
+    bool valid0 = false; int oa = 0, ob = -1; float e = 0.f;
+    if (r < len0) {
+        const Row0 m = match_of_row0(a, max0, arg0, arg1, r, len1);
+        valid0 = m.valid; e = m.e;
+        oa = a.ind[base0 + r];
+        ob = valid0 ? a.ind[base1 + m.j] : -1;
+        m0[oa] = ob;
+        s0[oa] = e;
+    }
+    const unsigned long long bal = __ballot(valid0);
+    const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) { sh_cnt[wave] = __popcll(bal); sh_below[wave] = below; }
+    __syncthreads();
+    int woff = sh_below[0] + sh_below[1] + sh_below[2] + sh_below[3];
+    for (int w = 0; w < wave; ++w) woff += sh_cnt[w];
+    if (valid0) {
+        int* ml = a.matches + (long long)pair * a.max_matches * 2;
+        float* msl = a.mscores + (long long)pair * a.max_matches;
+        const int k = woff + prefix;
+        ml[2 * k] = oa; ml[2 * k + 1] = ob; msl[k] = e;
+    }
+    if (blk == (int)gridDim.x - 1 && tid == 0)
+        a.n_matches[pair] = sh_below[0] + sh_below[1] + sh_below[2] + sh_below[3] + sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
 }
 
 // ---- optional: materialise the full log-assignment (ref :265-277) in original index space.
@@ -297,10 +327,10 @@ hipError_t launch_assign(const AssignArgs& a, hipStream_t s) {
     }
     }
     hipLaunchKernelGGL(lse_sweep_kernel, dim3(a.rs.cap0 / ART, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(col_lse_merge_kernel, dim3((a.rs.cap1 + 255) / 256, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(col_lse_merge_kernel, dim3(a.rs.cap1 / 64, B), dim3(256), 0, s, a);
     hipLaunchKernelGGL(argmax_sweep_kernel, dim3(a.rs.cap0 / ART, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(col_argmax_merge_kernel, dim3((a.rs.cap1 + 255) / 256, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(col_argmax_merge_kernel, dim3(a.rs.cap1 / 64, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(finalize_kernel, dim3((max(a.rs.cap0, a.rs.cap1) + 255) / 256, B), dim3(256), 0, s, a);
     if (a.log_assignment) {
         const long long total = (long long)B * (a.n0 + 1) * (a.n1 + 1);
         hipLaunchKernelGGL(fill_neg_inf_kernel, dim3(2048), dim3(256), 0, s, a.log_assignment, total);

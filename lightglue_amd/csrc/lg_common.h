@@ -181,6 +181,13 @@ template <class F> __device__ __forceinline__ void wave_allreduce2(float& x0, fl
     { const SwapPair p0 = swap32(x0), p1 = swap32(x1); x0 = p0.a; x1 = p1.a; merge(x0, x1, p0.b, p1.b); }
 }
 
+// single-value forms: every lane ends with the maximum / the sum over the 64 lanes (12 VALU ops, no LDS)
+__device__ __forceinline__ float wave_allmax(float x) {
+    x = vmax2(x, dpp_xor1(x)); x = vmax2(x, dpp_xor2(x)); x = vmax2(x, dpp_mov<0x141>(x)); x = vmax2(x, dpp_mov<0x140>(x));
+    return xor32_max(xor16_max(x));
+}
+__device__ __forceinline__ float wave_allsum(float x) { return xor32_sum(xor16_sum(row16_sum(x))); }
+
 // ---- wave helpers (wave = 64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

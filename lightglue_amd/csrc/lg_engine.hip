@@ -109,6 +109,8 @@ struct lg_engine {
     int attn_rows = 32;   // query rows per attention wave (32 | 64), option "attn_rows" / env LG_ATTN_ROWS
     int fused_tail = 1, fused_proj = 1, fused_next = 1, tail_variant = 0;   // tail_variant != 0: experiment builds only (lg_tail4.hip)
     int tail_timing = 0; long long* TAILDBG = nullptr;
+    int tail_row_tiles = 0;   // option "tail_row_tiles": 16-row tiles per fused-tail workgroup; 0 = by grid fill (4 | 2 | 1)
+    bool attn_auto_rows = true;   // small grids: 16 query rows per attention wave (twice the workgroups); off once "attn_rows" is set
     int tail_rows = 0;   // 0 = automatic, 64 / 128 = force the fused tail's rows per workgroup (option "tail_rows")
     // ---- workspace
     void* ws = nullptr; size_t ws_bytes = 0;
@@ -534,7 +536,8 @@ int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
 #endif
     if (std::strcmp(key, "fused_next") == 0) { e->fused_next = value != 0; return LG_OK; }
     if (std::strcmp(key, "attn_dma") == 0) { e->attn_dma = value != 0; return LG_OK; }
-    if (std::strcmp(key, "attn_rows") == 0) { if (value != 16 && value != 32 && value != 64) return fail(LG_ERR_INVALID, "attn_rows must be 16, 32 or 64"); e->attn_rows = value; return LG_OK; }
+    if (std::strcmp(key, "attn_rows") == 0) { if (value != 16 && value != 32 && value != 64) return fail(LG_ERR_INVALID, "attn_rows must be 16, 32 or 64"); e->attn_rows = value; e->attn_auto_rows = false; return LG_OK; }
+    if (std::strcmp(key, "tail_row_tiles") == 0) { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(LG_ERR_INVALID, "tail_row_tiles must be 0 (automatic), 1, 2 or 4"); e->tail_row_tiles = value; return LG_OK; }
     if (std::strcmp(key, "profile_only") == 0) { e->prof_only = value; return LG_OK; }   // kernel class index, -1 = all classes
     if (std::strcmp(key, "tail_timing") == 0) { e->tail_timing = value; return LG_OK; }   // 1: tail kernel, 2: self projection, 3: self attention (LG_ATTN_TIMING builds)
     return fail(LG_ERR_INVALID, std::string("unknown option '") + key + "'");
@@ -554,6 +557,18 @@ int lg_sp_sample_descriptors(const float* desc_map, int32_t batch, int32_t chann
 }
 
 namespace {
+// Fused tail: 16-row tiles per workgroup by grid fill.  A 64-row workgroup costs ~114k cycles (matrix-bound), a 32- / 16-row
+// one ~69k / ~58k (each streams the full weight set from L2): with R rows on 256 CUs take the shape with the shortest
+// critical path — 64 rows as soon as they fill the chip, smaller tiles for single pairs (B = 1, N = 1024: 32 -> 128 workgroups).
+int tail_row_tiles_for(int R) {
+    int best = 4; long long best_cost = -1;
+    const int shapes[3] = {4, 2, 1}; const long long cost[3] = {114, 69, 58};   // measured: 56 / 34 / 28.6 us per launch at B = 1, N = 1024
+    for (int i = 0; i < 3; ++i) {
+        const long long wgs = R / (16 * shapes[i]), rounds = (wgs + 255) / 256, c = rounds * cost[i];
+        if (best_cost < 0 || c < best_cost) { best = shapes[i]; best_cost = c; }
+    }
+    return best;
+}
 struct SpLayout { size_t mask_a, mask_b, nms, rows, cxy, csc, ctot, total; };
 SpLayout sp_layout(int B, int h, int w, int maxc) {
     SpLayout l{}; size_t off = 0;
@@ -785,7 +800,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 AttnArgs at{};
                 at.rs = rs_act; at.q = e->Q; at.k = e->K; at.vt = e->VT; at.ctx = e->CTX; at.R = R; at.cross = blk; at.scale_log2e = scale_log2e;
                 at.dbg = (e->tail_timing == 3 && blk == 0) ? e->TAILDBG : nullptr;
-                at.rows_per_wave = e->attn_rows; at.dma = e->attn_dma ? 1 : 0;
+                at.rows_per_wave = (e->attn_auto_rows && R / 128 * 4 < 256) ? 16 : e->attn_rows; at.dma = e->attn_dma ? 1 : 0;   // fewer 128-row workgroups than CUs: 64-row ones
                 TRY(prof_begin(e, blk == 0 ? PC_ATTN_SELF : PC_ATTN_CROSS, s));
                 HIPCHK(launch_attention(ap, at, s));
                 TRY(prof_end(e, s));
@@ -800,6 +815,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 ta.W2 = (blk ? e->w_ctail_2 : e->w_stail_2) + (size_t)i * e->tail_2_layer_bytes;
                 ta.b2 = (blk ? e->b_cf2 : e->b_sf2) + (size_t)i * D;
                 ta.dbg = e->tail_timing == 1 ? e->TAILDBG : nullptr;
+                ta.row_tiles = e->tail_row_tiles ? e->tail_row_tiles : tail_row_tiles_for(R);
                 // Across a layer boundary the fusion is valid whenever no row can MOVE in between: early stop alone only
                 // deactivates a pair (its speculative projection is never read), pruning re-orders rows — but it cannot
                 // happen while every segment is at or below the pruning threshold (ref :551 / :559; lengths only shrink).

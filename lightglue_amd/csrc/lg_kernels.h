@@ -66,6 +66,7 @@ struct TailArgs {
     const float* gamma; const float* beta;   // LayerNorm(512)
     const void* W2; const float* b2;         // [256][512] fragment-packed, [256]
     long long* dbg;                          // profiling tap: [blocks][8 waves][8] shader-clock stamps, or nullptr
+    int row_tiles;                           // 16-row tiles per workgroup: 4 (default; 0 = 4), 2 or 1 for under-filled grids (16-bit modes)
     // optional: the NEXT block's q/k/v projection, run on the x tile this kernel has just produced (next.W == nullptr:
     // none).  next.X is unused; supported for 16-bit operand / attention precisions (launch_tail_supports_next).
     ProjArgs next;

@@ -99,18 +99,18 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
             __builtin_amdgcn_sched_barrier(0);
             const char* tile = smA + (kc >> 1) * TILE;
 #pragma unroll
-            for (int mh = 0; mh < MT; mh += 4) {   // activation fragments of 4 row tiles at a time (bounds the live registers at MT = 8)
-            u32x4 afh[4][APART];
+            for (int mh = 0; mh < MT; mh += 4) {   // activation fragments of (up to) 4 row tiles at a time (bounds the live registers at MT = 8)
+            constexpr int MG = MT < 4 ? MT : 4;
+            u32x4 afh[MG][APART];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MG; ++mt)
 #pragma unroll
                 for (int p = 0; p < APART; ++p)
                     afh[mt][p] = *reinterpret_cast<const u32x4*>(tile + p * A_PLANE + lds_off<128>((mh + mt) * 16 + lr, (kc & 1) * 4 + g));
 #pragma unroll
-            for (int mtl = 0; mtl < 4; ++mtl)
+            for (int mtl = 0; mtl < MG; ++mtl)
 #pragma unroll
                 for (int j = 0; j < NTP; ++j) {
-                    constexpr int dummy = 0; (void)dummy;
                     const bool is_v = ((PASS * NTP + j) >> 1) >= N_QK;     // compile-time after unrolling
                     if (is_v) pj_mma<PREC, false>(acc[mh + mtl][j], bf[i][j], afh[mtl]);
                     else pj_mma<PREC, true>(acc[mh + mtl][j], bf[i][j], afh[mtl]);

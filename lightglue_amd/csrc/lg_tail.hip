@@ -38,7 +38,7 @@
 
 namespace lg {
 
-constexpr int TBM = 64, TTHREADS = 512;
+constexpr int TTHREADS = 512;
 
 template <int PREC> struct TT;
 template <> struct TT<PREC_F32> { typedef TagF32 Tag; static constexpr int KE = 32, NPART = 1; };
@@ -48,12 +48,12 @@ template <> struct TT<PREC_BF16X3> { typedef TagBF16 Tag; static constexpr int K
 
 // LDS map (bytes):  [0, G_BYTES) g tiles  — aliased during phase A by the two staging buffers
 //                   [G_BYTES, +RED_BYTES) cross-wave reduction scratch
-template <int PREC> struct TL {
+template <int PREC, int MT = 4> struct TL {
     static constexpr int STAGES = 512 / TT<PREC>::KE;               // K stages of the 512-long contractions
-    static constexpr int TILE = TBM * 128;                          // one plane of one stage: 64 rows x 128 B
+    static constexpr int TILE = MT * 16 * 128;                      // one plane of one stage: MT*16 rows x 128 B
     static constexpr int G_PLANE = STAGES * TILE;                   // 64 KB (16-bit) / 128 KB (f32)
     static constexpr int G_BYTES = TT<PREC>::NPART * G_PLANE;
-    static constexpr int RED_BYTES = 8 * TBM * 8;                   // (mean, M2) per row per wave
+    static constexpr int RED_BYTES = 8 * MT * 16 * 8;               // (mean, M2) per row per wave
     static constexpr int TOTAL = G_BYTES + RED_BYTES;
 };
 
@@ -98,15 +98,19 @@ __device__ __forceinline__ void tail_mma(f32x4& acc, const u32x4* wf, const u32x
 
 // NEXT: 0 = plain tail, 1 = + SelfBlock projection of the next layer (768 columns, rotary), 2 = + CrossBlock
 // projection (512 columns).  TA = element type of q/k/v (attention operand precision), only read when NEXT != 0.
-template <int PREC, int NEXT, class TA>
+// MT = 16-row tiles per workgroup: 4 (64 rows, the throughput shape) or 2 / 1 for under-filled grids (small batches): the
+// same per-row arithmetic in the same order — outputs are bit-identical — on 2x / 4x as many workgroups; each of them streams
+// the full weight set, so these shapes are L2-stream-bound per CU (~46k cycles) instead of matrix-bound.
+template <int PREC, int NEXT, class TA, int MT>
 __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
+    constexpr int TBM = 16 * MT;
     typedef typename TT<PREC>::Tag Tag;
     constexpr int EPC = Tag::EPC, KE = TT<PREC>::KE, NPART = TT<PREC>::NPART;
-    constexpr int STAGES = TL<PREC>::STAGES, TILE = TL<PREC>::TILE, G_PLANE = TL<PREC>::G_PLANE;
+    constexpr int STAGES = TL<PREC, MT>::STAGES, TILE = TL<PREC, MT>::TILE, G_PLANE = TL<PREC, MT>::G_PLANE;
     constexpr int NKC = 2 * STAGES;          // 16-byte k-chunks per row (16 for 16-bit, 32 for f32)
     constexpr int NV = EPC / 4;              // float4 loads per staged chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = reinterpret_cast<float*>(smem + TL<PREC>::G_BYTES);
+    float* red = reinterpret_cast<float*>(smem + TL<PREC, MT>::G_BYTES);
 
     const TileLoc t = locate_tile(a.rs, blockIdx.x, TBM);
     if (t.r0 >= a.rs.len[t.seg]) return;
@@ -123,9 +127,9 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
 
     // ------------------------------------------------------------------ phase A
-    f32x4 acc[4][4];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -137,32 +141,34 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     const void* Wc = a.Wcat;
     const void* W2 = a.W2;
 
-    // ---- activation tile -> LDS.  Half hf (0: x, 1: ctx) = 64 rows x 256 floats = STAGES/2 K-stage tiles.
-    // Thread -> (row = tid >> 3, 16-byte-chunk slot = tid & 7) of every stage tile of the half.
+    // ---- activation tile -> LDS.  Half hf (0: x, 1: ctx) = TBM rows x 256 floats = STAGES/2 K-stage tiles.
+    // A stage tile is TBM rows x 8 chunks of 16 bytes = 128 MT threads' worth, so the 512 threads cover 4 / MT stage tiles
+    // per round: thread -> (stage = round * 4/MT + tid / (128 MT), row = (tid >> 3) % TBM, chunk slot = tid & 7).
     constexpr int HS = STAGES / 2;                    // stage tiles per half (4, or 8 for f32)
-    const int srow = tid >> 3, sslot = tid & 7;
-    f32x4 hreg[HS][NV];
+    constexpr int SPR = 4 / MT, ROUNDS = HS / SPR;    // stage tiles per round, rounds per half
+    const int srow = (tid >> 3) & (TBM - 1), sslot = tid & 7, sst = tid / (128 * MT);
+    f32x4 hreg[ROUNDS][NV];
     auto load_half = [&](int hf) {
         const float* src = (hf ? a.CTX : a.X) + (long long)(t.grow0 + srow) * 256 + sslot * EPC;
 #pragma unroll
-        for (int st = 0; st < HS; ++st)
+        for (int i = 0; i < ROUNDS; ++i)
 #pragma unroll
-            for (int j = 0; j < NV; ++j) hreg[st][j] = *reinterpret_cast<const f32x4*>(src + st * KE + 4 * j);
+            for (int j = 0; j < NV; ++j) hreg[i][j] = *reinterpret_cast<const f32x4*>(src + (i * SPR + sst) * KE + 4 * j);
     };
     auto store_half = [&](int hf) {
         const int off = lds_off<128>(srow, sslot);
 #pragma unroll
-        for (int st = 0; st < HS; ++st) {
-            char* tile = smem + (hf * HS + st) * TILE;   // planes: p * G_PLANE
+        for (int i = 0; i < ROUNDS; ++i) {
+            char* tile = smem + (hf * HS + i * SPR + sst) * TILE;   // planes: p * G_PLANE
             if constexpr (PREC == PREC_F32) {
-                *reinterpret_cast<f32x4*>(tile + off) = hreg[st][0];
+                *reinterpret_cast<f32x4*>(tile + off) = hreg[i][0];
             } else if constexpr (PREC == PREC_BF16X3) {
                 u32x4 hi, lo;
-                split8_bf16(hreg[st][0], hreg[st][1], hi, lo);
+                split8_bf16(hreg[i][0], hreg[i][1], hi, lo);
                 *reinterpret_cast<u32x4*>(tile + off) = hi;
                 *reinterpret_cast<u32x4*>(tile + G_PLANE + off) = lo;
             } else {
-                *reinterpret_cast<u32x4*>(tile + off) = pack8<Tag>(hreg[st][0], hreg[st][1]);
+                *reinterpret_cast<u32x4*>(tile + off) = pack8<Tag>(hreg[i][0], hreg[i][1]);
             }
         }
     };
@@ -179,17 +185,17 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             for (int p = 0; p < NPART; ++p) dst[nt][p] = wfrag(Wc, p, 512LL * 512, w + 8 * nt, kc);
     };
     // activation fragments of one k-chunk (4 row tiles x planes) from the LDS-resident tile
-    auto read_af = [&](u32x4 (&af)[4][NPART], int kc) {
+    auto read_af = [&](u32x4 (&af)[MT][NPART], int kc) {
         const char* tile = smem + (kc >> 1) * TILE;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int p = 0; p < NPART; ++p)
                 af[mt][p] = *reinterpret_cast<const u32x4*>(tile + p * G_PLANE + lds_off<128>(mt * 16 + lr, (kc & 1) * 4 + g));
     };
-    auto mma_A = [&](const u32x4 (&af)[4][NPART], const u32x4 (&b)[4][NPART]) {
+    auto mma_A = [&](const u32x4 (&af)[MT][NPART], const u32x4 (&b)[4][NPART]) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) tail_mma<PREC>(acc[mt][nt], b[nt], af[mt]);
     };
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     // the wave index provably uniform (SGPR address parts) the kernel has the 32 VGPRs for it, and the ~200-cycle LDS round
     // trip at the head of every chunk — which both waves of a SIMD hit at the same time — disappears.  The prefetch stays
     // inside a half (the other half is not in LDS yet); a half's first chunk reads its own.
-    u32x4 afr[2][4][NPART];
+    u32x4 afr[2][MT][NPART];
 #pragma unroll 1
     for (int hf = 0; hf < 2; ++hf) {
         read_af(afr[0], hf * HC);
@@ -237,12 +243,12 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bcat + col);
             gam[nt] = *reinterpret_cast<const f32x4*>(a.gamma + col); bet[nt] = *reinterpret_cast<const f32x4*>(a.beta + col);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] += b4;
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] += b4;
         }
         // this wave's 64 hidden units of row (mt, lr): local mean and M2 = sum (h - mean)^2, entirely in registers
         f32x2* red2 = reinterpret_cast<f32x2*>(red);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             float sacc = 0.f;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) sacc += (acc[mt][nt][0] + acc[mt][nt][1]) + (acc[mt][nt][2] + acc[mt][nt][3]);
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         }
         __syncthreads();   // also: every wave is past its last read of the activation tile -> g may overwrite it below
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             // merge the 8 (count 64, mean, M2) triples of the row: mean = avg(mean_w), M2 = sum M2_w + 64 sum (mean_w - mean)^2
             const f32x4* pr = reinterpret_cast<const f32x4*>(red2 + (mt * 16 + lr) * 8);
             const f32x4 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     // a lane's 4 values are 4 consecutive k of one row = one 8-byte piece per plane (f32: one 16-byte piece).
     auto gelu_store = [&](int j) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             const f32x2 v01 = gelu_fast2(f32x2{acc[mt][j][0], acc[mt][j][1]});
             const f32x2 v23 = gelu_fast2(f32x2{acc[mt][j][2], acc[mt][j][3]});
             const int row = mt * 16 + lr;
@@ -302,9 +308,9 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         }
     };
     // acc2[mt][nt][r] = out[row mt*16 + lr][column w*32 + nt*16 + 4g + r]
-    f32x4 acc2[4][2];
+    f32x4 acc2[MT][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { acc2[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int i = 0; i < MT; ++i) { acc2[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     u32x4 b2f[4][2][NPART];   // ring, 3 k-chunks ahead
     auto load_b_B = [&](u32x4 (&dst)[2][NPART], int kc) {
 #pragma unroll
@@ -314,14 +320,14 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     };
     auto chunk_B = [&](int kc, const u32x4 (&b)[2][NPART]) {
         const char* tile = smem + (kc >> 1) * TILE;
-        u32x4 af[4][NPART];
+        u32x4 af[MT][NPART];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int p = 0; p < NPART; ++p)
                 af[mt][p] = *reinterpret_cast<const u32x4*>(tile + p * G_PLANE + lds_off<128>(mt * 16 + lr, (kc & 1) * 4 + g));
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) tail_mma<PREC>(acc2[mt][nt], b[nt], af[mt]);
     };
@@ -331,12 +337,12 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     stamp(3);
     constexpr int CPS = NKC / 4;   // k-chunks per step (4 for 16-bit: K-stages 2j, 2j+1; 8 for f32)
     const int qlen = a.rs.len[t.seg];
-    f32x4 xres[4][2];              // residual rows, same (row, 4 columns) per lane as acc2
+    f32x4 xres[MT][2];             // residual rows, same (row, 4 columns) per lane as acc2
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (j == 3) {              // issue the residual loads so that they land under the last step's MFMAs
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
                     xres[mt][nt] = *reinterpret_cast<const f32x4*>(a.X + (long long)(t.grow0 + mt * 16 + lr) * 256 + w * 32 + nt * 16 + 4 * g);
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         const int col = w * 32 + nt * 16 + 4 * g;
         const f32x4 b2 = b2v[nt];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             const int row = mt * 16 + lr;
             const f32x4 xn = xres[mt][nt] + (acc2[mt][nt] + b2);
             if (t.r0 + row < qlen) *reinterpret_cast<f32x4*>(a.X + (long long)(t.grow0 + row) * 256 + col) = xn;
@@ -379,19 +385,27 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         }
     }
     stamp(5);
-    if constexpr (NEXT != 0) proj_compute<(PREC == PREC_BF16X3 ? PREC_QKV_F16W2 : PREC), TA, NEXT == 1 ? 3 : 2, 2, G_PLANE>(a.next, t, smem, 8);
+    if constexpr (NEXT != 0) proj_compute<(PREC == PREC_BF16X3 ? PREC_QKV_F16W2 : PREC), TA, NEXT == 1 ? 3 : 2, 2, G_PLANE, MT>(a.next, t, smem, 8);
     if (a.dbg && lane == 0)   // wall clock at the end + where the workgroup ran (HW_ID, XCC_ID)
         a.dbg[((long long)blockIdx.x * 8 + w) * 8 + 7] = (wall_clock64() & ((1LL << 44) - 1)) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFF00) << 40) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 44);
 }
 
-template <int PREC, int NEXT, class TA> static hipError_t launch_tail_t(const TailArgs& a, hipStream_t s) {
+template <int PREC, int NEXT, class TA, int MT> static hipError_t launch_tail_m(const TailArgs& a, hipStream_t s) {
     const int R = a.rs.B * (a.rs.cap0 + a.rs.cap1);
-    auto kern = tail_kernel<PREC, NEXT, TA>;
-    constexpr int smem = TL<PREC>::TOTAL;
+    auto kern = tail_kernel<PREC, NEXT, TA, MT>;
+    constexpr int smem = TL<PREC, MT>::TOTAL;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(R / TBM), dim3(TTHREADS), smem, s, a);
+    hipLaunchKernelGGL(kern, dim3(R / (16 * MT)), dim3(TTHREADS), smem, s, a);
     return hipGetLastError();
+}
+template <int PREC, int NEXT, class TA> static hipError_t launch_tail_t(const TailArgs& a, hipStream_t s) {
+    if constexpr (PREC == PREC_F32) return launch_tail_m<PREC, NEXT, TA, 4>(a, s);   // (the exact mode keeps one shape)
+    else {
+        if (a.row_tiles == 1 && !a.dbg) return launch_tail_m<PREC, NEXT, TA, 1>(a, s);
+        if (a.row_tiles == 2 && !a.dbg) return launch_tail_m<PREC, NEXT, TA, 2>(a, s);
+        return launch_tail_m<PREC, NEXT, TA, 4>(a, s);
+    }
 }
 template <int PREC, class TA> static hipError_t launch_tail_next(const TailArgs& a, hipStream_t s) {
     if (!a.next.W) return launch_tail_t<PREC, 0, TA>(a, s);

@@ -426,6 +426,27 @@ def test_attention_lds_dma_kernel_is_bit_identical(precision):
         assert torch.isfinite(dma["matching_scores0"]).all() and (dma["matches0"] > -1).any(), (n0, n1)
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+def test_tail_row_tile_shapes_are_bit_identical(precision):
+    """The fused tail runs 64-row workgroups when they fill the chip and 32- / 16-row ones for small grids (engine option
+    tail_row_tiles: 0 = by grid fill, 4 | 2 | 1 = forced).  The per-row arithmetic and its order do not depend on the shape, so
+    every output must be BIT-identical across shapes — fused next projection included; ragged, adaptive and batched cases."""
+    require_gpu()
+    for (b, n0, n1, recipe, kw) in ((3, 300, 333, "A", dict(depth_confidence=-1, width_confidence=-1)), (2, 130, 520, "B", dict(pruning_min_kpts=64)),
+                                    (1, 1024, 1024, "A", dict(depth_confidence=-1, width_confidence=-1)), (2, 40, 700, "C", dict())):
+        sd = synth.make_state_dict(0, recipe=recipe)
+        model = gpu_util.make_model(sd, precision, **kw)
+        data = gpu_util.to_torch(synth.make_batch(31, b, n0, n1))
+        outs = {}
+        for shape in (4, 2, 1, 0):
+            model.set_option("tail_row_tiles", shape)
+            outs[shape] = model(data)
+        for shape in (2, 1, 0):
+            for key in ("matches0", "matches1", "matching_scores0", "matching_scores1", "prune0", "prune1"):
+                assert torch.equal(outs[4][key], outs[shape][key]), (b, n0, n1, shape, key)
+            assert torch.equal(torch.as_tensor(outs[4]["stop"]), torch.as_tensor(outs[shape]["stop"]))
+
+
 def test_product_library_has_no_experiment_variants():
     """The streaming tail variants and the LG_* environment switches exist in experiment builds only (-DLG_EXPERIMENTS)."""
     require_gpu()

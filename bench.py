@@ -310,15 +310,16 @@ def main():
             out = step()
     drain()
 
-    def mfma_clock():
+    def mfma_sustained():
+        # what the matrix pipe of THIS box sustains (dense bf16 MFMA spin, ~25 ms): TFLOP/s and the shader clock it ran at
         import ctypes as C
         from lightglue_amd import _cabi
-        v = C.c_double(0.0)
+        tf, mhz = C.c_double(0.0), C.c_double(0.0)
         with torch.cuda.device(dev):
-            _cabi.check(_cabi.load().lg_debug_mfma_clock_mhz(C.byref(v), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-        return round(v.value, 1)
+            _cabi.check(_cabi.load().lg_debug_mfma_sustained(C.byref(tf), C.byref(mhz), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return round(tf.value, 1), round(mhz.value, 1)
 
-    clock_before = mfma_clock()
+    sustained_tflops, sustained_mhz = mfma_sustained()
     model.profile(True, dev, only=dom_class)
     barrier()
     t0 = time.perf_counter()
@@ -378,7 +379,10 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dom + (" (+ next block's q/k/v projection)" if fused_next and dom == "fused_tail" else ""), "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": PMC_TRAFFIC_BYTES.get((args.precision, B, n, dom + ("+next" if fused_next and dom == "fused_tail" else ""))), "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE passes of this same command, profiles/r02a_pmc_{fetch,write}.md — a constant from those passes, not re-measured inside this run",
                          "avg_launch_ms": dom_ms, "algorithmic_flops_per_launch": fl[dom],
-                         "note": "algorithmic FLOPs (2/MAC) of one launch / HIP-event launch duration; split-bf16 issues 3 MFMAs per algorithmic MAC"},
+                         "sustained_peak": sustained_tflops, "frac_of_sustained": (achieved / sustained_tflops if sustained_tflops else None),
+                         "note": "algorithmic FLOPs (2/MAC) of one launch / HIP-event launch duration; split-bf16 issues 3 MFMAs per algorithmic MAC "
+                                 "(2 in the fused q/k/v projection).  peak = nominal dense bf16 (2.4 GHz); sustained_peak = what a dense bf16 MFMA spin "
+                                 "reaches on THIS box right before the timed region (power-managed clock, see effective_mfma_clock_mhz)"},
             # the HBM-bound stage of the path: dual log-softmax + argmax sweeps over the similarity matrix
             "roofline_hbm": ({"bound": "hbm", "kernel": "assign (lse_sweep + argmax_sweep + merges + finalize)",
                               "achieved": hbm_bytes_assign(B, n, m) / (timed["assign"][0] / timed["assign"][1] * 1e-3) / 1e9,
@@ -394,7 +398,7 @@ def main():
             "algorithmic_tflops": value * flops_per_pair(n, m) / 1e12,
             # shader clock this box sustains under a matrix-core-dense load, measured right before the timed region: the pool's
             # boxes differ by up to ~20 % for one binary, and most of it is this clock
-            "effective_mfma_clock_mhz": clock_before,
+            "effective_mfma_clock_mhz": sustained_mhz, "sustained_dense_bf16_tflops": sustained_tflops,
             "matches_per_pair": float(np.mean([(o > -1).sum().item() for o in out["matches0"]])) if "matches0" in out else None,
         }
         # match-index parity of the batch that was just timed (rank 0's pairs): against the reference's own fixture for the

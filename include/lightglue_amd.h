@@ -121,8 +121,9 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream);
 int lg_engine_set_option(lg_engine* e, const char* key, int32_t value);
 
 /* ---- test / profiling taps (not used by the product path) ---- */
-/* Effective shader clock in MHz under a ~2 ms matrix-core-dense load (explains box-to-box throughput differences of one binary). */
-int lg_debug_mfma_clock_mhz(double* mhz, void* hip_stream);
+/* What the matrix pipe sustains on this box: dense bf16 MFMA spin on every SIMD for ~25 ms -> achieved TFLOP/s and the shader
+ * clock it ran at (the nominal 2.5 PFLOP/s assumes 2.4 GHz; explains box-to-box throughput differences of one binary). */
+int lg_debug_mfma_sustained(double* tflops, double* mhz, void* hip_stream);
 /* Stop the next forwards after pipeline step `step` (-1 = run everything).  Step numbering:
  * 0 = prep (+input projection); 1 + 12*layer + k, k = 0 self-QKV, 1 self-attention, 2 out_proj,
  * 3 ffn.0, 4 LayerNorm+GELU, 5 ffn.3+residual, 6 cross-QK/V, 7 cross-attention, 8 to_out, 9 ffn.0,

@@ -629,40 +629,46 @@ int lg_sp_detect(const float* scores, int32_t batch, int32_t h, int32_t w, int32
 }
 
 namespace {
-// matrix-core-dense spin: every wave issues independent 16x16x32 bf16 MFMAs; block 0 / wave 0 reports its shader-clock span
-__global__ __launch_bounds__(512) void mfma_clock_kernel(long long* cycles, int iters) {
+// matrix-core-dense spin: 2 waves per SIMD, 8 independent accumulators per wave (the pipe never waits), operands with
+// pseudo-random bits (data that toggles: an all-zero spin runs ~15 % faster at the same power); block 0 reports its
+// shader-clock span
+__global__ __launch_bounds__(512) void mfma_spin_kernel(long long* cycles, int iters) {
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-    bf16x8_t x, y;
-    for (int i = 0; i < 8; ++i) { x[i] = (__bf16)(0.001f * (threadIdx.x & 63) + i); y[i] = (__bf16)(1.0f + 0.01f * i); }
+    const unsigned h = (threadIdx.x * 2654435761u + blockIdx.x * 40503u) * 12345u;
+    u32x4 xa = {h ^ 0x3f803f80u, (h >> 3) | 0x3c003c00u, (h * 7u) & 0x3fff3fffu, (h * 13u) & 0x3fff3fffu};
+    u32x4 xb = {(h * 3u) & 0x3fff3fffu, (h * 5u) & 0x3fff3fffu, (h * 11u) & 0x3fff3fffu, (h * 17u) & 0x3fff3fffu};
     f32x4 acc[8];
     for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const long long t0 = clock64();
     for (int it = 0; it < iters; ++it) {
-        asm volatile("" : "+v"(x), "+v"(y));
+        asm volatile("" : "+v"(xa), "+v"(xb));
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, acc[i], 0, 0, 0);
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, xa), __builtin_bit_cast(bf16x8_t, xb), acc[i], 0, 0, 0);
     }
     const long long t1 = clock64();
     float sacc = 0.f;
     for (int i = 0; i < 8; ++i) sacc += acc[i][0];
-    if (blockIdx.x == 0 && threadIdx.x == 0) { cycles[0] = t1 - t0; cycles[1] = sacc == 12345.f; }
+    // the LONGEST wave span: the arbiter issues oldest-first, so the older wave of a SIMD can finish in half the kernel's time
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(cycles), (unsigned long long)(t1 - t0));
+    if (sacc == 12345.f) cycles[1] = 1;
 }
 }  // namespace
 
-/* Effective shader clock (MHz) while every SIMD issues MFMAs back to back for ~1-2 ms: clock64() span of one wave / HIP-event
- * duration of the launch.  The pool's MI355X boxes sustain different clocks under matrix load (power management), which is what
- * separates "fast" and "slow" boxes for the same binary; bench.py reports it next to the throughput. */
-int lg_debug_mfma_clock_mhz(double* mhz, void* hip_stream) {
-    if (!mhz) return fail(LG_ERR_INVALID, "null pointer");
+/* What the matrix pipe SUSTAINS on this box: a dense v_mfma_f32_16x16x32_bf16 spin on every SIMD for ~25 ms (long enough for
+ * the power management to settle).  tflops = achieved dense bf16 rate (the nominal 2.5 PFLOP/s assumes 2.4 GHz; under this load
+ * the boxes of the pool hold 1.8 - 2.1 GHz), mhz = shader clock during the spin (s_memtime span of one wave / HIP-event time). */
+int lg_debug_mfma_sustained(double* tflops, double* mhz, void* hip_stream) {
+    if (!tflops || !mhz) return fail(LG_ERR_INVALID, "null pointer");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     long long* d = nullptr;
     HIPCHK(hipMalloc(&d, 16));
     hipEvent_t a, b;
     HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-    const int iters = 20000;
-    hipLaunchKernelGGL(mfma_clock_kernel, dim3(256), dim3(512), 0, s, d, iters / 10);   // warm-up / clock ramp
+    const int iters = 400000;
+    hipLaunchKernelGGL(mfma_spin_kernel, dim3(256), dim3(512), 0, s, d, iters / 10);   // warm-up / clock ramp
+    HIPCHK(hipMemsetAsync(d, 0, 16, s));
     HIPCHK(hipEventRecord(a, s));
-    hipLaunchKernelGGL(mfma_clock_kernel, dim3(256), dim3(512), 0, s, d, iters);
+    hipLaunchKernelGGL(mfma_spin_kernel, dim3(256), dim3(512), 0, s, d, iters);
     HIPCHK(hipEventRecord(b, s));
     HIPCHK(hipEventSynchronize(b));
     float ms = 0.f; long long h[2] = {0, 0};
@@ -670,6 +676,7 @@ int lg_debug_mfma_clock_mhz(double* mhz, void* hip_stream) {
     HIPCHK(hipMemcpy(h, d, 16, hipMemcpyDeviceToHost));
     (void)hipFree(d); (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     *mhz = ms > 0.f ? (double)h[0] / (ms * 1e3) : 0.0;
+    *tflops = ms > 0.f ? 256.0 * 8.0 * iters * 8.0 * 16384.0 / (ms * 1e9) : 0.0;
     return LG_OK;
 }
 

@@ -108,3 +108,18 @@ def match_batch(matcher, feats0: list, feats1: list) -> list:
             "stop": int(stop[b]) if torch.is_tensor(stop) else stop,
         })
     return out
+
+
+def cm_prune(prune):
+    """RGBA colour per keypoint from the matcher's ``prune0`` / ``prune1`` output (the layer at which a point was
+    dropped; points alive to the end carry the maximum) — the consumer the reference ships for that output
+    (``lightglue/viz2d.py:33-39`` with its ``cm_BlRdGn`` ramp, :22-31): survivors blue, the others red (dropped after
+    layer 1) -> yellow -> green (layer 10).  Pure numpy: returns ``[N, 4]`` floats in [0, 1] for any plotting backend."""
+    import numpy as np
+    p = np.asarray(prune.detach().cpu() if isinstance(prune, torch.Tensor) else prune, dtype=np.float64)
+    t = np.where(p == p.max(), -1.0, (p - 1.0) / 9.0)              # -1 marks the survivors
+    up = 2.0 * np.clip(t, 0.0, 1.0)[..., None]                       # red (0) -> green (1)
+    ramp = up * np.array([0.0, 1.0, 0.0, 1.0]) + (2.0 - up) * np.array([1.0, 0.0, 0.0, 1.0])
+    dn = -2.0 * np.clip(t, -1.0, 0.0)[..., None]                     # red (0) -> blue (-1)
+    blue = dn * np.array([0.0, 0.1, 1.0, 1.0]) + (2.0 - dn) * np.array([1.0, 0.0, 0.0, 1.0])
+    return np.clip(np.where(t[..., None] < 0.0, blue, ramp), 0.0, 1.0)

@@ -150,6 +150,25 @@ def test_extracted_to_image_frame_matches_reference_formula():
     assert torch.equal(feats["keypoints"], kp)   # input not mutated
 
 
+def test_cm_prune_colours_the_prune_output_like_the_reference():
+    """ref viz2d.py:33-39 (cm_prune) over :22-31 (cm_BlRdGn): survivors blue, dropped points red -> green by layer.
+    Compared live against the reference function when /root/reference (and matplotlib, which its module imports) is there."""
+    import numpy as np
+    from lightglue_amd import cm_prune
+    prune = torch.tensor([1, 2, 5, 9, 10, 10, 3])
+    c = cm_prune(prune)
+    assert c.shape == (7, 4) and np.all((c >= 0) & (c <= 1))
+    assert np.allclose(c[4], [0.0, 0.2, 1.0, 1.0]) and np.allclose(c[5], c[4])            # alive to the end
+    assert np.allclose(c[0], [1.0, 0.0, 0.0, 1.0])                                          # dropped after the first layer: red
+    assert np.allclose(c[2], [1.0, 8.0 / 9.0, 0.0, 1.0]) and np.allclose(c[3], [2.0 / 9.0, 1.0, 0.0, 1.0])
+    import importlib.util, pathlib
+    ref = pathlib.Path("/root/reference/lightglue/viz2d.py")
+    if ref.exists() and importlib.util.find_spec("matplotlib") is not None:
+        spec = importlib.util.spec_from_file_location("ref_viz2d", ref); mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+        for p in (prune, torch.tensor([0, 1, 4, 4]), torch.tensor([3, 3, 3])):
+            assert np.allclose(cm_prune(p), mod.cm_prune(p)), p
+
+
 def test_model_can_be_deep_copied_and_pickled():
     """The reference module can be copied / pickled; the process-local engine handle must not get in the way."""
     import copy, pickle

@@ -227,6 +227,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per step")
     ap.add_argument("--kpts", type=int, default=N_KPTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the 25 ms dense-MFMA spin that measures what the box sustains (profiling runs)")
     ap.add_argument("--no-fuse-next", action="store_true", help="run the q/k/v projections as their own kernels instead of inside the previous block's tail kernel")
     ap.add_argument("--unfused", action="store_true", help="use the per-op kernels instead of the fused block tail")
     args = ap.parse_args()
@@ -319,7 +320,7 @@ def main():
             _cabi.check(_cabi.load().lg_debug_mfma_sustained(C.byref(tf), C.byref(mhz), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         return round(tf.value, 1), round(mhz.value, 1)
 
-    sustained_tflops, sustained_mhz = mfma_sustained()
+    sustained_tflops, sustained_mhz = (None, None) if args.no_calibration else mfma_sustained()
     model.profile(True, dev, only=dom_class)
     barrier()
     t0 = time.perf_counter()

@@ -114,10 +114,16 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream);
  *   "tail_variant" 0  product library: only 0 (lg_tail.hip) is accepted.  Experiment builds (make EXPERIMENTS=1 / -DLG_EXPERIMENTS) add
  *                     the lg_tail4.hip decompositions 1 = 4 waves x 64 rows, 2 = 8 waves x 128 rows, 3 = 4 waves x 32 rows (all
  *                     correct, none faster) and the LG_TAIL_VARIANT / LG_ATTN_ROWS environment switches; the product reads no environment
- *   "attn_rows"    32 query rows per attention wave: 16 | 32 | 64 (bit-identical outputs)
+ *   "attn_rows"    -  query rows per attention wave: 16 | 32 | 64 (bit-identical outputs).  Unset: 32, and 16 when a launch has
+ *                     fewer 128-row workgroups than the chip has CUs (single pairs); setting it pins the shape
+ *   "attn_dma"     1  16-bit, 32 rows per wave: K / V^T tiles reach LDS by DMA (two buffers, one barrier per tile, 4 waves per
+ *                     SIMD); 0 = the register-staged kernel (bit-identical)
+ *   "tail_row_tiles" 0  16-row tiles per fused-tail workgroup: 4 (64 rows) | 2 | 1, 0 = by grid fill (small grids take the
+ *                     smaller shapes; bit-identical outputs; the exact fp32 mode always uses 4)
  *   "profile_only" -1 restrict the HIP-event timing of lg_engine_profile_enable to one kernel class (index of
  *                     lg_profile_class_name), -1 = all classes
- *   "tail_timing"  0  shader-clock taps: 1 tail kernel, 2 self projection, 3 attention (LG_ATTN_TIMING builds) */
+ *   "tail_timing"  0  shader-clock taps: 1 tail kernel (+ wall-clock life span and CU of every workgroup, tools/tail_wall.py),
+ *                     2 self projection, 3 attention (LG_ATTN_TIMING / LG_ATTN_WALL builds) */
 int lg_engine_set_option(lg_engine* e, const char* key, int32_t value);
 
 /* ---- test / profiling taps (not used by the product path) ---- */

@@ -62,15 +62,15 @@ def flops_per_launch(pairs: int, n: int, m: int):
 
 
 # HBM bytes per launch of the dominant kernel measured with rocprofv3 PMC passes (FETCH_SIZE x 2 per the gfx950
-# correction in MI355X_MICROARCH.md + WRITE_SIZE; KB in the tables), profiles/r02a_pmc_{fetch,write}.md; valid for the default
+# correction in MI355X_MICROARCH.md + WRITE_SIZE; KB in the tables), profiles/r02d_pmc_{fetch,write}.md; valid for the default
 # workload only.  "+next": the tail kernel that also runs the next block's projection: average over the 8 launches with a
 # SelfBlock projection (NEXT = 1), the 9 with a CrossBlock projection (NEXT = 2) and the last, plain one (NEXT = 0).
-PMC_TRAFFIC_BYTES = {("bf16x3", 32, 1024, "fused_tail"): (2 * 1.217e5 + 9.828e4) * 1024,
-                     ("bf16x3", 32, 1024, "fused_tail+next"): (8 * (2 * 1.434e5 + 1.954e5) + 9 * (2 * 1.275e5 + 1.62e5)
-                                                               + (2 * 1.217e5 + 9.828e4)) / 18 * 1024}
+PMC_TRAFFIC_BYTES = {("bf16x3", 32, 1024, "fused_tail"): (2 * 1.2e5 + 9.281e4) * 1024,
+                     ("bf16x3", 32, 1024, "fused_tail+next"): (8 * (2 * 1.433e5 + 1.932e5) + 9 * (2 * 1.275e5 + 1.602e5)
+                                                               + (2 * 1.2e5 + 9.281e4)) / 18 * 1024}
 
 
-# the two log-assignment sweeps (profiles/r02a_pmc_{fetch,write}.md): 2 x FETCH_SIZE + WRITE_SIZE of lse_sweep + argmax_sweep
+# the two log-assignment sweeps (profiles/r02d_pmc_{fetch,write}.md): 2 x FETCH_SIZE + WRITE_SIZE of lse_sweep + argmax_sweep
 PMC_TRAFFIC_ASSIGN = {("bf16x3", 32, 1024): (2 * 6.556e4 + 8320 + 2 * 6.671e4 + 8448) * 1024}
 
 
@@ -378,7 +378,7 @@ def main():
                                    + (" (split-bf16 MFMA x3 for linear layers + f16 attention, fp32 accumulate/residual)" if args.precision == "bf16x3" else ""),
                        "pairs_per_gpu": B, "keypoints": n, "parallelism": f"pair-sharded dp{world}"},
             "roofline": {"bound": "mfma", "kernel": dom + (" (+ next block's q/k/v projection)" if fused_next and dom == "fused_tail" else ""), "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": PMC_TRAFFIC_BYTES.get((args.precision, B, n, dom + ("+next" if fused_next and dom == "fused_tail" else ""))), "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE passes of this same command, profiles/r02a_pmc_{fetch,write}.md — a constant from those passes, not re-measured inside this run",
+                         "traffic": PMC_TRAFFIC_BYTES.get((args.precision, B, n, dom + ("+next" if fused_next and dom == "fused_tail" else ""))), "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE passes of this same command, profiles/r02d_pmc_{fetch,write}.md — a constant from those passes, not re-measured inside this run",
                          "avg_launch_ms": dom_ms, "algorithmic_flops_per_launch": fl[dom],
                          "sustained_peak": sustained_tflops, "frac_of_sustained": (achieved / sustained_tflops if sustained_tflops else None),
                          "note": "algorithmic FLOPs (2/MAC) of one launch / HIP-event launch duration; split-bf16 issues 3 MFMAs per algorithmic MAC "
@@ -391,7 +391,7 @@ def main():
                               "frac": hbm_bytes_assign(B, n, m) / (timed["assign"][0] / timed["assign"][1] * 1e-3) / 1e9 / 8000.0,
                               "algorithmic_bytes_per_launch": hbm_bytes_assign(B, n, m),
                               "traffic": PMC_TRAFFIC_ASSIGN.get((args.precision, B, n)),
-                              "traffic_source": "profiles/r02a_pmc_{fetch,write}.md (constant from the PMC passes, not re-measured in this run)"} if "assign" in timed else None),
+                              "traffic_source": "profiles/r02d_pmc_{fetch,write}.md (constant from the PMC passes, not re-measured in this run)"} if "assign" in timed else None),
             "kernel_ms_per_step": kernel_ms,
             "kernel_ms_per_step_source": ("HIP events around every launch during the warm-up steps; the roofline kernel's entry and "
                                           "avg_launch_ms come from events inside the timed region") if warm_prof else "HIP events inside the timed region",

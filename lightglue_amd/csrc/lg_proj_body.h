@@ -14,7 +14,7 @@ constexpr int PBM = 64, PTHREADS = 512;
 // Operand scheme of the projection.  NPART = weight planes, APART = activation planes.
 // PREC_QKV_F16W2 is what the default precision ("bf16x3") uses for the q/k/v projections: the activation tile as ONE f16
 // plane, the weights as split f16 (hi + lo), i.e. TWO MFMAs per product instead of the three of split-bf16.  q/k/v leave
-// this kernel rounded to f16 for the attention anyway, so rounding x to f16 first costs nothing measurable (oracle study,
+// this kernel rounded to f16 for the attention anyway, so rounding x to f16 first costs nothing measurable (operand-rounding study,
 // max |dscore| 2.3-3.0e-4 vs 2.2-2.5e-4 for split-bf16; a single f16 product would give 1.0-1.6e-3).
 constexpr int PREC_QKV_F16W2 = 100;
 template <int PREC> struct PJ;

@@ -227,6 +227,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per step")
     ap.add_argument("--kpts", type=int, default=N_KPTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="one GPU: synchronous forward per step (no deferred output assembly)")
     ap.add_argument("--no-calibration", action="store_true", help="skip the 25 ms dense-MFMA spin that measures what the box sustains (profiling runs)")
     ap.add_argument("--no-fuse-next", action="store_true", help="run the q/k/v projections as their own kernels instead of inside the previous block's tail kernel")
     ap.add_argument("--unfused", action="store_true", help="use the per-op kernels instead of the fused block tail")
@@ -277,12 +278,18 @@ def main():
             # every gather is waited for (and unpacked) one step later, the last one before the closing barrier
             prev, pending[0] = pending[0], sharded.issue_local(data, B * world)
             return prev.wait() if prev is not None else None
-        return model(data)
+        if args.no_pipeline:
+            return model(data)
+        # one GPU: the forward's only host synchronisation (the ragged match lists need their sizes) is taken one step later
+        # (LightGlue.forward_deferred), so Python assembles the outputs of step i while step i + 1 runs; every step's full
+        # output dict is built inside the timed region, the last one before the closing barrier
+        prev, pending[0] = pending[0], model.forward_deferred(data)
+        return prev.result() if prev is not None else None
 
     def drain():
-        if sharded is not None and pending[0] is not None:
+        if pending[0] is not None:
             last, pending[0] = pending[0], None
-            return last.wait()
+            return last.wait() if sharded is not None else last.result()
         return None
 
     def barrier():
@@ -376,7 +383,10 @@ def main():
             "config": {"workload": f"SuperPoint-dim 256-d descriptors, N=M={n}, 9 layers, pruning/early-stop OFF, batch={B} pairs per GPU, "
                                    f"seeded random weights (recipe A), precision={args.precision}"
                                    + (" (split-bf16 MFMA x3 for linear layers + f16 attention, fp32 accumulate/residual)" if args.precision == "bf16x3" else ""),
-                       "pairs_per_gpu": B, "keypoints": n, "parallelism": f"pair-sharded dp{world}"},
+                       "pairs_per_gpu": B, "keypoints": n, "parallelism": f"pair-sharded dp{world}",
+                       "host_pipelining": ("result gather of step i overlaps the forward of step i+1" if world > 1 else
+                                           "synchronous forward per step" if args.no_pipeline else
+                                           "output assembly (the forward's one host sync) of step i overlaps the forward of step i+1; all K outputs are built inside the timed region")},
             "roofline": {"bound": "mfma", "kernel": dom + (" (+ next block's q/k/v projection)" if fused_next and dom == "fused_tail" else ""), "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": PMC_TRAFFIC_BYTES.get((args.precision, B, n, dom + ("+next" if fused_next and dom == "fused_tail" else ""))), "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE passes of this same command, profiles/r02d_pmc_{fetch,write}.md — a constant from those passes, not re-measured inside this run",
                          "avg_launch_ms": dom_ms, "algorithmic_flops_per_launch": fl[dom],

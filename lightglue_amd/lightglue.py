@@ -60,6 +60,20 @@ def _cross_block(d: int) -> nn.Module:  # ref :176-192
     return m
 
 
+class DeferredMatches:
+    """Handle of a forward whose outputs are on their way (LightGlue.forward_deferred)."""
+
+    def __init__(self, done, host_sizes, assemble):
+        self._done, self._host, self._assemble, self._out = done, host_sizes, assemble, None
+
+    def result(self) -> dict:
+        if self._out is None:
+            self._done.synchronize()
+            self._out = self._assemble(self._host.tolist())
+            self._assemble = None
+        return self._out
+
+
 class LightGlue(nn.Module):
     default_conf = {
         "name": "lightglue",
@@ -303,8 +317,15 @@ class LightGlue(nn.Module):
         `PairShardedMatcher`, which puts exactly these on the wire (int32 is enough for N <= 4096; the API widens to int64)."""
         return self.forward(data, _raw=True)
 
+    def forward_deferred(self, data: dict) -> "DeferredMatches":
+        """The forward enqueued WITHOUT its host synchronisation: `.result()` of the returned handle waits for this forward
+        only (an event), then builds the same dict as `forward`.  A caller that issues forward i + 1 before it asks for the
+        result of forward i keeps the GPU busy while Python assembles the ragged lists (bench.py does; the reference's
+        synchronous `forward` cannot)."""
+        return self.forward(data, _defer=True)
+
     @torch.no_grad()
-    def forward(self, data: dict, _raw: bool = False) -> dict:
+    def forward(self, data: dict, _raw: bool = False, _defer: bool = False) -> dict:
         """Match keypoints and descriptors between two images (same dict contract as ref :456-481).
 
         Input (dict):  image0/image1: {keypoints [B,N,2], descriptors [B,N,D], image_size [B,2] (optional),
@@ -421,27 +442,36 @@ class LightGlue(nn.Module):
             if num1 is not None:
                 prune1 = prune1 * (torch.arange(n, device=device)[None] < num1[:, None])
         stop64 = ipiece(i64, 5, 2, b)[0]
-        host = stop_nm.tolist()  # THE host sync of the forward: the ragged lists need their sizes (and B = 1 its `stop`)
-        counts = host[1]
-        matches = [row[:c] for row, c in zip(mlist64.unbind(0), counts)]
-        mscores = [row[:c] for row, c in zip(mscore_list.unbind(0), counts)]
-        if not do_early_stop and not do_point_pruning and m > 0 and n > 0 and not ragged:
-            stop_out = conf.n_layers if b == 1 else torch.full((b,), conf.n_layers, device=device, dtype=torch.long)
-        else:
-            stop_out = int(host[0][0]) if b == 1 else stop64
-        extra_out = {} if log_assignment is None else {"log_assignment": log_assignment}
-        return {
-            **extra_out,
-            "matches0": m0_64,
-            "matches1": m1_64,
-            "matching_scores0": ms0,
-            "matching_scores1": ms1,
-            "stop": stop_out,
-            "matches": matches,
-            "scores": mscores,
-            "prune0": prune0,
-            "prune1": prune1,
-        }
+
+        def assemble(host):   # host = [[stop per pair], [matches per pair]]
+            counts = host[1]
+            matches = [row[:c] for row, c in zip(mlist64.unbind(0), counts)]
+            mscores = [row[:c] for row, c in zip(mscore_list.unbind(0), counts)]
+            if not do_early_stop and not do_point_pruning and m > 0 and n > 0 and not ragged:
+                stop_out = conf.n_layers if b == 1 else torch.full((b,), conf.n_layers, device=device, dtype=torch.long)
+            else:
+                stop_out = int(host[0][0]) if b == 1 else stop64
+            extra_out = {} if log_assignment is None else {"log_assignment": log_assignment}
+            return {
+                **extra_out,
+                "matches0": m0_64,
+                "matches1": m1_64,
+                "matching_scores0": ms0,
+                "matching_scores1": ms1,
+                "stop": stop_out,
+                "matches": matches,
+                "scores": mscores,
+                "prune0": prune0,
+                "prune1": prune1,
+            }
+
+        if _defer:   # the sizes travel to pinned host memory behind an event; nothing waits here
+            hbuf = torch.empty((2, b), dtype=torch.int32, pin_memory=True)
+            hbuf.copy_(stop_nm, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(device))
+            return DeferredMatches(done, hbuf, assemble)
+        return assemble(stop_nm.tolist())  # THE host sync of the forward: the ragged lists need their sizes (and B = 1 its `stop`)
 
     def set_option(self, key: str, value: int, device="cuda"):
         """Engine options (include/lightglue_amd.h lg_engine_set_option), e.g. ("fused_tail", 0)."""

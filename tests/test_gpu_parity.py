@@ -447,6 +447,25 @@ def test_tail_row_tile_shapes_are_bit_identical(precision):
             assert torch.equal(torch.as_tensor(outs[4]["stop"]), torch.as_tensor(outs[shape]["stop"]))
 
 
+def test_deferred_forward_gives_the_same_dict():
+    """forward_deferred: the host synchronisation of forward i is taken after forward i + 1 has been enqueued; the handles'
+    results must equal the synchronous forwards' outputs (ragged lists included), in issue order and in reverse."""
+    require_gpu()
+    sd = synth.make_state_dict(0, recipe="C")
+    model = gpu_util.make_model(sd, "bf16x3")
+    batches = [gpu_util.to_torch(synth.make_batch(41 + i, 2, 300 + 40 * i, 333)) for i in range(3)]
+    want = [model(d) for d in batches]
+    handles = [model.forward_deferred(d) for d in batches]
+    got = [h.result() for h in reversed(handles)][::-1]
+    for w, g in zip(want, got):
+        for key in ("matches0", "matches1", "matching_scores0", "matching_scores1", "prune0", "prune1"):
+            assert torch.equal(w[key], g[key]), key
+        assert torch.equal(torch.as_tensor(w["stop"]), torch.as_tensor(g["stop"]))
+        assert len(w["matches"]) == len(g["matches"]) and all(torch.equal(a, b) for a, b in zip(w["matches"], g["matches"]))
+        assert all(torch.equal(a, b) for a, b in zip(w["scores"], g["scores"]))
+    assert handles[0].result() is got[0]      # cached
+
+
 def test_product_library_has_no_experiment_variants():
     """The streaming tail variants and the LG_* environment switches exist in experiment builds only (-DLG_EXPERIMENTS)."""
     require_gpu()

@@ -169,6 +169,20 @@ def test_cm_prune_colours_the_prune_output_like_the_reference():
             assert np.allclose(cm_prune(p), mod.cm_prune(p)), p
 
 
+def test_deferred_handle_synchronises_once_and_caches():
+    """DeferredMatches (LightGlue.forward_deferred): .result() waits for ITS event, assembles once, then returns the same dict."""
+    from lightglue_amd.lightglue import DeferredMatches
+    calls = []
+
+    class Ev:
+        def synchronize(self):
+            calls.append("sync")
+
+    h = DeferredMatches(Ev(), torch.tensor([[9, 9], [3, 1]], dtype=torch.int32), lambda host: (calls.append("assemble"), {"sizes": host})[1])
+    out = h.result()
+    assert out == {"sizes": [[9, 9], [3, 1]]} and h.result() is out and calls == ["sync", "assemble"]
+
+
 def test_model_can_be_deep_copied_and_pickled():
     """The reference module can be copied / pickled; the process-local engine handle must not get in the way."""
     import copy, pickle

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""CPU study (oracle + operand-rounding emulation, no GPU): could the two CROSS terms of a split-bf16 product run on the fp8 matrix
+path?   x w = hi(x) hi(w) + hi(x) lo(w) + lo(x) hi(w)  with hi / lo bf16 is what the HIP path issues for the FFN chain (3 bf16
+MFMAs).  gfx950's v_mfma_scale_f32_16x16x128_f8f6f4 runs fp8 at twice the bf16 rate with a shared power-of-two scale per 32-element
+block (MX): the two cross terms as ONE fp8 instruction each would make the product cost 2 bf16-equivalents instead of 3 — if
+rounding hi(x), hi(w) (and the lo planes) to e4m3 inside the cross terms keeps the match scores within the 1e-3 bar.
+Emulation: per contraction class, product = bf16hi(a) bf16hi(b) + q8(hi a) q8(lo b) + q8(lo a) q8(hi b), q8 = e4m3 with MX block
+scaling along K.   usage: tools/study_fp8_cross.py [N] [seeds]"""
+import sys
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+from oracle import lightglue_oracle as O
+from lightglue_amd import synthetic as synth
+
+
+def q_e4m3_mx(x, axis):
+    """Round to fp8 e4m3 with one power-of-two scale per 32-element block along `axis` (MX): block max -> [256, 448]."""
+    x = np.moveaxis(np.asarray(x, np.float64), axis, -1)
+    k = x.shape[-1]; pad = (-k) % 32
+    xp = np.pad(x, [(0, 0)] * (x.ndim - 1) + [(0, pad)]).reshape(*x.shape[:-1], -1, 32)
+    amax = np.abs(xp).max(-1, keepdims=True)
+    e = np.floor(np.log2(np.where(amax > 0, amax, 1.0)))
+    scale = 2.0 ** (e - 8)                              # amax / scale in [256, 512): clipped to 448 below
+    v = xp / scale
+    mag = np.abs(v)
+    ex = np.floor(np.log2(np.where(mag > 0, mag, 1.0)))
+    ex = np.maximum(ex, -6)                             # subnormals: fixed step 2^-9
+    step = 2.0 ** (ex - 3)
+    q = np.clip(np.round(v / step) * step, -448, 448)
+    out = (q * scale).reshape(*x.shape[:-1], -1)[..., :k]
+    return np.moveaxis(out, -1, axis)
+
+
+class Ctx8(O._Ctx):
+    fp8_classes = ()
+    hi = "bf16"       # precision of the hi planes (the main product runs on the 16-bit matrix path): "bf16" | "fp16"
+
+    def mm(self, a, b, where="lin"):
+        if where in self.fp8_classes:
+            rnd = O.round_bf16 if self.hi == "bf16" else O.round_fp16
+            a64, b64 = np.asarray(a, np.float64), np.asarray(b, np.float64)
+            ha, hb = rnd(a.astype(np.float32)).astype(np.float64), rnd(b.astype(np.float32)).astype(np.float64)
+            la, lb = a64 - ha, b64 - hb                      # (rounded to fp8 below)
+            y = ha @ hb + q_e4m3_mx(ha, -1) @ q_e4m3_mx(lb, -2) + q_e4m3_mx(la, -1) @ q_e4m3_mx(hb, -2)
+            return y.astype(self.dtype)
+        return super().mm(a, b, where)
+
+
+def run(sd, conf, data, classes, hi="bf16"):
+    Ctx8.fp8_classes = classes; Ctx8.hi = hi
+    orig = O._Ctx
+    O._Ctx = Ctx8
+    try:
+        return O.forward(sd, conf, data, quant=O.DEFAULT_PRECISION_QUANT)
+    finally:
+        O._Ctx = orig
+
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+conf = O.make_conf(depth_confidence=-1, width_confidence=-1)
+ALL = ("lin_ffn0", "lin_ffn3", "lin_out")
+rows = [("default precision (split-bf16 x3; q/k/v f16 x2)", (), "bf16"),
+        ("bf16 hi planes: ffn.0 cross terms in fp8", ("lin_ffn0",), "bf16"), ("bf16 hi planes: ffn.0 + ffn.3 + out_proj", ALL, "bf16"),
+        ("f16 hi planes: ffn.0 cross terms in fp8", ("lin_ffn0",), "fp16"), ("f16 hi planes: ffn.3 cross terms in fp8", ("lin_ffn3",), "fp16"),
+        ("f16 hi planes: out_proj cross terms in fp8", ("lin_out",), "fp16"), ("f16 hi planes: ffn.0 + ffn.3 + out_proj", ALL, "fp16"),
+        ("f16 hi planes: the same + final_proj / similarity", ALL + ("final",), "fp16")]
+res = {name: [] for name, _, _ in rows}
+for seed in range(seeds):
+    sd = synth.make_state_dict(seed, recipe="A")
+    data = synth.make_batch(100 + seed, 1, n, n)
+    ref = O.forward(sd, conf, data)
+    for name, classes, hi in rows:
+        out = run(sd, conf, data, classes, hi)
+        flips = int((out["matches0"] != ref["matches0"]).sum())
+        res[name].append((flips, float(np.abs(out["matching_scores0"] - ref["matching_scores0"]).max())))
+    print("seed", seed, {k: v[-1] for k, v in res.items()}, flush=True)
+print(f"\nN = M = {n}, {seeds} seeds, vs the fp32 oracle: index flips / max |dscore|")
+for name, _, _ in rows:
+    print(f"  {name:58s} flips {sum(f for f, _ in res[name]):3d}   max |dscore| {max(d for _, d in res[name]):.2e}")

@@ -16,13 +16,12 @@ from lightglue_amd import synthetic as synth
 
 
 def q_e4m3_mx(x, axis):
-    """Round to fp8 e4m3 with one power-of-two scale per 32-element block along `axis` (MX): block max -> [256, 448]."""
+    """Round to fp8 e4m3 with one power-of-two scale per 32-element block along `axis` (MX): block max -> (224, 448]."""
     x = np.moveaxis(np.asarray(x, np.float64), axis, -1)
     k = x.shape[-1]; pad = (-k) % 32
     xp = np.pad(x, [(0, 0)] * (x.ndim - 1) + [(0, pad)]).reshape(*x.shape[:-1], -1, 32)
     amax = np.abs(xp).max(-1, keepdims=True)
-    e = np.floor(np.log2(np.where(amax > 0, amax, 1.0)))
-    scale = 2.0 ** (e - 8)                              # amax / scale in [256, 512): clipped to 448 below
+    scale = 2.0 ** np.ceil(np.log2(np.where(amax > 0, amax, 1.0) / 448.0))   # smallest power of two with amax / scale <= 448 (no clipping)
     v = xp / scale
     mag = np.abs(v)
     ex = np.floor(np.log2(np.where(mag > 0, mag, 1.0)))
@@ -33,8 +32,25 @@ def q_e4m3_mx(x, axis):
     return np.moveaxis(out, -1, axis)
 
 
+def q_e2m3_mx(x, axis):
+    """Round to fp6 e2m3 (max 7.5, subnormal step 0.125) with one power-of-two scale per 32-element block (MX)."""
+    x = np.moveaxis(np.asarray(x, np.float64), axis, -1)
+    k = x.shape[-1]; pad = (-k) % 32
+    xp = np.pad(x, [(0, 0)] * (x.ndim - 1) + [(0, pad)]).reshape(*x.shape[:-1], -1, 32)
+    amax = np.abs(xp).max(-1, keepdims=True)
+    scale = 2.0 ** np.ceil(np.log2(np.where(amax > 0, amax, 1.0) / 7.5))     # smallest power of two with amax / scale <= 7.5
+    v = xp / scale
+    mag = np.abs(v)
+    ex = np.maximum(np.floor(np.log2(np.where(mag > 0, mag, 1.0))), 0)     # below 1.0: subnormal, step 2^-3
+    step = 2.0 ** (ex - 3)
+    q = np.clip(np.round(v / step) * step, -7.5, 7.5)
+    out = (q * scale).reshape(*x.shape[:-1], -1)[..., :k]
+    return np.moveaxis(out, -1, axis)
+
+
 class Ctx8(O._Ctx):
     fp8_classes = ()
+    fmt = "fp8"       # cross-term format: "fp8" (e4m3) | "fp6" (e2m3, twice the fp8 rate on gfx950)
     hi = "bf16"       # precision of the hi planes (the main product runs on the 16-bit matrix path): "bf16" | "fp16"
 
     def mm(self, a, b, where="lin"):
@@ -43,13 +59,14 @@ class Ctx8(O._Ctx):
             a64, b64 = np.asarray(a, np.float64), np.asarray(b, np.float64)
             ha, hb = rnd(a.astype(np.float32)).astype(np.float64), rnd(b.astype(np.float32)).astype(np.float64)
             la, lb = a64 - ha, b64 - hb                      # (rounded to fp8 below)
-            y = ha @ hb + q_e4m3_mx(ha, -1) @ q_e4m3_mx(lb, -2) + q_e4m3_mx(la, -1) @ q_e4m3_mx(hb, -2)
+            q = q_e2m3_mx if self.fmt == "fp6" else q_e4m3_mx
+            y = ha @ hb + q(ha, -1) @ q(lb, -2) + q(la, -1) @ q(hb, -2)
             return y.astype(self.dtype)
         return super().mm(a, b, where)
 
 
 def run(sd, conf, data, classes, hi="bf16"):
-    Ctx8.fp8_classes = classes; Ctx8.hi = hi
+    Ctx8.fp8_classes = classes; Ctx8.hi = hi.split("+")[0]; Ctx8.fmt = "fp6" if hi.endswith("+fp6") else "fp8"
     orig = O._Ctx
     O._Ctx = Ctx8
     try:
@@ -66,9 +83,16 @@ rows = [("default precision (split-bf16 x3; q/k/v f16 x2)", (), "bf16"),
         ("bf16 hi planes: ffn.0 cross terms in fp8", ("lin_ffn0",), "bf16"), ("bf16 hi planes: ffn.0 + ffn.3 + out_proj", ALL, "bf16"),
         ("f16 hi planes: ffn.0 cross terms in fp8", ("lin_ffn0",), "fp16"), ("f16 hi planes: ffn.3 cross terms in fp8", ("lin_ffn3",), "fp16"),
         ("f16 hi planes: out_proj cross terms in fp8", ("lin_out",), "fp16"), ("f16 hi planes: ffn.0 + ffn.3 + out_proj", ALL, "fp16"),
-        ("f16 hi planes: the same + final_proj / similarity", ALL + ("final",), "fp16")]
+        ("f16 hi planes: the same + final_proj / similarity", ALL + ("final",), "fp16"),
+        ("f16 hi planes, cross terms in fp6 e2m3: ffn.0 + ffn.3 + out_proj", ALL, "fp16+fp6"),
+        ("f16 hi planes, cross terms in fp6 e2m3: out_proj", ("lin_out",), "fp16+fp6")]
+import os
+if os.environ.get("STUDY_ROWS"):   # e.g. STUDY_ROWS="default,f16 hi planes: ffn.0 + ffn.3" keeps the rows whose name contains one of the keys
+    keys = os.environ["STUDY_ROWS"].split(",")
+    rows = [r for r in rows if any(k in r[0] for k in keys)]
+seed0 = int(os.environ.get("STUDY_SEED0", "0"))
 res = {name: [] for name, _, _ in rows}
-for seed in range(seeds):
+for seed in range(seed0, seed0 + seeds):
     sd = synth.make_state_dict(seed, recipe="A")
     data = synth.make_batch(100 + seed, 1, n, n)
     ref = O.forward(sd, conf, data)
@@ -79,4 +103,4 @@ for seed in range(seeds):
     print("seed", seed, {k: v[-1] for k, v in res.items()}, flush=True)
 print(f"\nN = M = {n}, {seeds} seeds, vs the fp32 oracle: index flips / max |dscore|")
 for name, _, _ in rows:
-    print(f"  {name:58s} flips {sum(f for f, _ in res[name]):3d}   max |dscore| {max(d for _, d in res[name]):.2e}")
+    print(f"  {name:70s} flips {sum(f for f, _ in res[name]):3d}   max |dscore| {max(d for _, d in res[name]):.2e}")

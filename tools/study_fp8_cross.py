@@ -64,9 +64,30 @@ class Ctx8(O._Ctx):
             return y.astype(self.dtype)
         return super().mm(a, b, where)
 
+    # ---- "folded" mode: ffn.0 as the HIP tail kernel computes it — out_proj folded into the ctx half of ONE 512-long
+    # contraction  h = x W1x^T + ctx (W1m Wo)^T + (b1 + W1m bo)  — so that the two halves can get different operand formats
+    folded = False
+
+    def linear(self, x, w, b=None, where="lin"):
+        if self.folded and where == "lin_out":
+            y = (np.asarray(x, np.float64) @ np.asarray(w, np.float64).T + np.asarray(b, np.float64)).astype(self.dtype)
+            self._stash = getattr(self, "_stash", []) + [(y, x, w, b)]
+            return y
+        if self.folded and where == "lin_ffn0":
+            d = x.shape[-1] // 2
+            msg = x[..., d:]
+            hit = [i for i, e in enumerate(self._stash) if e[0].shape == msg.shape and np.array_equal(e[0], msg)]
+            _, ctx_in, wo, bo = self._stash.pop(hit[0])
+            w1x, w1m = np.asarray(w[:, :d], np.float64), np.asarray(w[:, d:], np.float64)
+            wf = (w1m @ np.asarray(wo, np.float64)).astype(np.float32)            # the host folds in double and stores fp32 before splitting
+            bf = np.asarray(b, np.float64) + w1m @ np.asarray(bo, np.float64)
+            y = self.mm(x[..., :d], w1x.astype(np.float32).T, "fold_x").astype(np.float64) + self.mm(ctx_in, wf.T, "fold_ctx").astype(np.float64) + bf
+            return y.astype(self.dtype)
+        return super().linear(x, w, b, where)
+
 
 def run(sd, conf, data, classes, hi="bf16"):
-    Ctx8.fp8_classes = classes; Ctx8.hi = hi.split("+")[0]; Ctx8.fmt = "fp6" if hi.endswith("+fp6") else "fp8"
+    Ctx8.fp8_classes = classes; Ctx8.hi = hi.split("+")[0]; Ctx8.fmt = "fp6" if "+fp6" in hi else "fp8"; Ctx8.folded = hi.endswith("+folded")
     orig = O._Ctx
     O._Ctx = Ctx8
     try:
@@ -85,7 +106,12 @@ rows = [("default precision (split-bf16 x3; q/k/v f16 x2)", (), "bf16"),
         ("f16 hi planes: out_proj cross terms in fp8", ("lin_out",), "fp16"), ("f16 hi planes: ffn.0 + ffn.3 + out_proj", ALL, "fp16"),
         ("f16 hi planes: the same + final_proj / similarity", ALL + ("final",), "fp16"),
         ("f16 hi planes, cross terms in fp6 e2m3: ffn.0 + ffn.3 + out_proj", ALL, "fp16+fp6"),
-        ("f16 hi planes, cross terms in fp6 e2m3: out_proj", ("lin_out",), "fp16+fp6")]
+        ("f16 hi planes, cross terms in fp6 e2m3: out_proj", ("lin_out",), "fp16+fp6"),
+        ("folded ffn.0 (as the HIP kernel), default operands", (), "fp16+fp6+folded"),
+        ("folded: ctx half in f16 + fp6 cross terms", ("fold_ctx",), "fp16+fp6+folded"),
+        ("folded: ctx half + ffn.3", ("fold_ctx", "lin_ffn3"), "fp16+fp6+folded"),
+        ("folded: ctx half + x half", ("fold_ctx", "fold_x"), "fp16+fp6+folded"),
+        ("folded: ctx half + x half + ffn.3", ("fold_ctx", "fold_x", "lin_ffn3"), "fp16+fp6+folded")]
 import os
 if os.environ.get("STUDY_ROWS"):   # e.g. STUDY_ROWS="default,f16 hi planes: ffn.0 + ffn.3" keeps the rows whose name contains one of the keys
     keys = os.environ["STUDY_ROWS"].split(",")

@@ -40,6 +40,15 @@ namespace lg {
 
 constexpr int TTHREADS = 512;
 
+// Scheduling experiments (tools/build_variant.sh <name> -DLG_TAIL_STEP_ORDER=1 ...; the product build leaves both at 0 and its
+// machine code is unchanged by them).  Every setting computes the same values in the same order per element.
+#ifndef LG_TAIL_STEP_ORDER
+#define LG_TAIL_STEP_ORDER 0    // 1: waves 0..3 apply the next GELU BEFORE the step's MFMAs; 2: GELU interleaved with the MFMAs in-wave
+#endif
+#ifndef LG_TAIL_GELU_SCALAR
+#define LG_TAIL_GELU_SCALAR 0   // 1: the erf polynomial in scalar v_fma_f32 instead of v_pk_fma_f32 (packed f32 overlaps MFMAs of the other wave badly)
+#endif
+
 template <int PREC> struct TT;
 template <> struct TT<PREC_F32> { typedef TagF32 Tag; static constexpr int KE = 32, NPART = 1; };
 template <> struct TT<PREC_BF16> { typedef TagBF16 Tag; static constexpr int KE = 64, NPART = 1; };
@@ -82,6 +91,29 @@ __device__ __forceinline__ f32x2 gelu_fast2(f32x2 u) {
     const f32x2 sgn = {copysignf(er[0], x[0]), copysignf(er[1], x[1])};
     return half_u + half_u * sgn;
 }
+#if LG_TAIL_GELU_SCALAR
+// the same arithmetic, one value at a time (v_fma_f32 / v_mul_f32: every packed operation above is the IEEE operation on each half)
+__device__ __forceinline__ float gelu_fast1(float u) {
+    const float x = u * 0.70710678118654752440f;
+    const float ax = fabsf(x);
+    const float tt = __builtin_amdgcn_rcpf(__builtin_fmaf(ax, 0.3275911f, 1.0f));
+    float p = __builtin_fmaf(tt, -0.0779742014f, 0.151737503f);
+    p = __builtin_fmaf(p, tt, 0.39572154f);
+    p = __builtin_fmaf(p, tt, -0.574341196f);
+    p = __builtin_fmaf(p, tt, 0.810336914f);
+    p = __builtin_fmaf(p, tt, -0.151473053f);
+    p = __builtin_fmaf(p, tt, 0.270560832f);
+    p = __builtin_fmaf(p, tt, 0.175431661f);
+    p = p * tt;
+    const float e = __builtin_amdgcn_exp2f(ax * ax * -1.44269504088896340736f);
+    const float er = __builtin_fmaf(-p, e, 1.0f);
+    const float half_u = u * 0.5f;
+    return __builtin_fmaf(half_u, copysignf(er, x), half_u);
+}
+__device__ __forceinline__ f32x2 gelu_pair(f32x2 u) { return f32x2{gelu_fast1(u[0]), gelu_fast1(u[1])}; }
+#else
+__device__ __forceinline__ f32x2 gelu_pair(f32x2 u) { return gelu_fast2(u); }
+#endif
 
 // acc (C^T tile) += w x^T for one k-chunk; split-bf16: (w_hi x_lo) + (w_lo x_hi) + (w_hi x_hi)
 template <int PREC>
@@ -289,8 +321,8 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     auto gelu_store = [&](int j) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const f32x2 v01 = gelu_fast2(f32x2{acc[mt][j][0], acc[mt][j][1]});
-            const f32x2 v23 = gelu_fast2(f32x2{acc[mt][j][2], acc[mt][j][3]});
+            const f32x2 v01 = gelu_pair(f32x2{acc[mt][j][0], acc[mt][j][1]});
+            const f32x2 v23 = gelu_pair(f32x2{acc[mt][j][2], acc[mt][j][3]});
             const int row = mt * 16 + lr;
             if constexpr (EPC == 8) {
                 char* dst = smem + (2 * j + (w >> 2)) * TILE + lds_off<128>(row, (w & 3) * 2 + (g >> 1)) + (g & 1) * 8;
@@ -347,6 +379,41 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
                 for (int nt = 0; nt < 2; ++nt)
                     xres[mt][nt] = *reinterpret_cast<const f32x4*>(a.X + (long long)(t.grow0 + mt * 16 + lr) * 256 + w * 32 + nt * 16 + 4 * g);
         }
+#if LG_TAIL_STEP_ORDER != 0
+        auto step_mma = [&]() {
+#pragma unroll
+            for (int i = 0; i < CPS; ++i) {
+                const int kc = j * CPS + i;
+                load_b_B(b2f[(kc + 3) & 3], kc + 3 < NKC ? kc + 3 : NKC - 1);
+                chunk_B(kc, b2f[kc & 3]);
+            }
+        };
+#endif
+#if LG_TAIL_STEP_ORDER == 1
+        // experiment: the two waves of a SIMD (w, w + 4) take the step's two halves in OPPOSITE order, so that one's GELU (VALU)
+        // faces the other's MFMAs instead of both queueing for the same pipe; same arithmetic per wave -> bit-identical outputs
+        if (j < 3 && w < 4) {
+            gelu_store(j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            step_mma();
+        } else {
+            step_mma();
+            if (j < 3) gelu_store(j + 1);
+        }
+        if (j < 3) __syncthreads();
+#elif LG_TAIL_STEP_ORDER == 2
+        // experiment: the next n-tile's GELU interleaved INSIDE the wave with this step's MFMAs (3 VALU per MFMA issue slot)
+        step_mma();
+        if (j < 3) {
+            gelu_store(j + 1);
+#pragma unroll
+            for (int i = 0; i < 96; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x402, 3, 0);   // three VALU / transcendental
+            }
+            __syncthreads();
+        }
+#else
 #pragma unroll
         for (int i = 0; i < CPS; ++i) {
             const int kc = j * CPS + i;
@@ -357,6 +424,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             gelu_store(j + 1);
             __syncthreads();
         }
+#endif
     }
     stamp(4);
     // ------------------------------------------------------------------ epilogue: + b2, + x, store; next block's activation tile

@@ -22,8 +22,11 @@ enum {
     LG_PREC_F32 = 0,    /* v_mfma_f32_16x16x4_f32: exact fp32 products (parity anchor)            */
     LG_PREC_BF16 = 1,   /* v_mfma_f32_16x16x32_bf16                                                */
     LG_PREC_F16 = 2,    /* v_mfma_f32_16x16x32_f16                                                 */
-    LG_PREC_BF16X3 = 3  /* split bf16 (hi+lo, 3 MFMAs) for linear layers / similarity; attention
+    LG_PREC_BF16X3 = 3, /* split bf16 (hi+lo, 3 MFMAs) for linear layers / similarity; attention
                            runs in f16 like the reference's GPU path (lightglue.py:119)          */
+    LG_PREC_F16X3 = 4   /* the same split scheme on f16 planes (same cost, ~100x smaller product
+                           error in emulation; needs |x| < 65504).  Opt-in: built, NOT yet
+                           validated on the GPU                           */
 };
 
 #define LG_OK 0

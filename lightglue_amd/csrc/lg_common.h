@@ -32,7 +32,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // Operand precision of a contraction (host enum mirrored in include/lightglue_amd.h)
-enum : int { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2, PREC_BF16X3 = 3 };
+enum : int { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2, PREC_BF16X3 = 3, PREC_F16X3 = 4 };
+// PREC_F16X3 (opt-in, NOT yet validated on the GPU): the split scheme of PREC_BF16X3 on f16 planes — same three MFMAs and bytes per
+// product; hi carries 11 bits instead of 8, so the dropped lo*lo term and the lo rounding are 2^-24-class instead of 2^-17-class
+// (emulated product error 3.5e-9 vs 3.6e-7 of sum |x||w|, tools/study_product_error.py).  Needs |x| < 65504 (the reference's own
+// fp16 mode needs the same).
+__host__ __device__ constexpr bool prec_is_split(int prec) { return prec == PREC_BF16X3 || prec == PREC_F16X3; }
 
 // Element tags
 struct TagF32 { typedef float elem; static constexpr int EPC = 4; };   // elements per 16-byte chunk
@@ -87,6 +92,18 @@ __device__ __forceinline__ void split8_bf16(const f32x4& a, const f32x4& b, u32x
     hi[0] = pack2_bf16(h[0], h[1]); hi[1] = pack2_bf16(h[2], h[3]); hi[2] = pack2_bf16(h[4], h[5]); hi[3] = pack2_bf16(h[6], h[7]);
     lo[0] = pack2_bf16(l[0], l[1]); lo[1] = pack2_bf16(l[2], l[3]); lo[2] = pack2_bf16(l[4], l[5]); lo[3] = pack2_bf16(l[6], l[7]);
 }
+
+// split-f16: x = hi + lo, both f16 (lo of small values lives in f16 subnormals, which the MFMA honours)
+__device__ __forceinline__ void split8_f16(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
+    float h[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { h[i] = (float)(f16_t)a[i]; l[i] = a[i] - h[i]; h[4 + i] = (float)(f16_t)b[i]; l[4 + i] = b[i] - h[4 + i]; }
+    hi[0] = pack2_f16(h[0], h[1]); hi[1] = pack2_f16(h[2], h[3]); hi[2] = pack2_f16(h[4], h[5]); hi[3] = pack2_f16(h[6], h[7]);
+    lo[0] = pack2_f16(l[0], l[1]); lo[1] = pack2_f16(l[2], l[3]); lo[2] = pack2_f16(l[4], l[5]); lo[3] = pack2_f16(l[6], l[7]);
+}
+template <class Tag> __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo);
+template <> __device__ __forceinline__ void split8<TagBF16>(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) { split8_bf16(a, b, hi, lo); }
+template <> __device__ __forceinline__ void split8<TagF16>(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) { split8_f16(a, b, hi, lo); }
 
 // ---- LDS tile addressing.  A tile is [rows][ROWB bytes] with ROWB = 128 or 256; the 16-byte
 // slot index within a row is XOR-swizzled with a function of the row so that the 16-lane groups of

@@ -151,8 +151,14 @@ int upload_packed(int prec, const float* src, size_t n, PackedW& dst, size_t ele
             for (size_t i = 0; i < n; ++i) q[i] = f32_to_bf16(src[i] - bf16_to_f32(p[i]));
         }
     }
+    if (prec == PREC_F16X3) {   // (the branch above wrote bf16: redo both planes in f16)
+        auto* p = reinterpret_cast<uint16_t*>(hi.data());
+        lo.resize(n * es);
+        auto* q = reinterpret_cast<uint16_t*>(lo.data());
+        for (size_t i = 0; i < n; ++i) { p[i] = f32_to_f16(src[i]); q[i] = f32_to_f16(src[i] - f16_to_f32(p[i])); }
+    }
     HIPCHK(hipMemcpy(static_cast<char*>(dst.hi) + elem_offset * es, hi.data(), n * es, hipMemcpyHostToDevice));
-    if (prec == PREC_BF16X3) HIPCHK(hipMemcpy(static_cast<char*>(dst.lo) + elem_offset * es, lo.data(), n * es, hipMemcpyHostToDevice));
+    if (prec_is_split(prec)) HIPCHK(hipMemcpy(static_cast<char*>(dst.lo) + elem_offset * es, lo.data(), n * es, hipMemcpyHostToDevice));
     return LG_OK;
 }
 
@@ -161,7 +167,8 @@ int upload_packed(int prec, const float* src, size_t n, PackedW& dst, size_t ele
 int upload_fragment_packed(int prec, const std::vector<double>& W, int rows, int K, char* dst, bool split_f16 = false) {
     const size_t es = elem_size(prec);
     const int EPC = prec == PREC_F32 ? 4 : 8, KC = 4 * EPC, NKC = K / KC, NT = rows / 16;
-    const bool split = prec == PREC_BF16X3;
+    const bool split = prec_is_split(prec);
+    if (prec == PREC_F16X3) split_f16 = true;   // both planes f16
     const size_t n = (size_t)rows * K;
     std::vector<char> buf(n * es * (split ? 2 : 1));
     for (int nt = 0; nt < NT; ++nt)
@@ -332,11 +339,11 @@ int lg_engine_create(const lg_config* cfg, lg_engine** out) {
     if (cfg->descriptor_dim != 256 || cfg->num_heads != 4) return fail(LG_ERR_INVALID, "only descriptor_dim=256, num_heads=4 (head_dim 64) are built");
     if (cfg->n_layers < 1 || cfg->n_layers > 64) return fail(LG_ERR_INVALID, "bad n_layers");
     if (cfg->input_dim <= 0 || cfg->input_dim % 64) return fail(LG_ERR_INVALID, "input_dim must be a positive multiple of 64");
-    if (cfg->precision < 0 || cfg->precision > 3) return fail(LG_ERR_INVALID, "bad precision");
+    if (cfg->precision < 0 || cfg->precision > LG_PREC_F16X3) return fail(LG_ERR_INVALID, "bad precision");
     auto* e = new lg_engine();
     e->cfg = *cfg;
     int ap = cfg->attn_precision;
-    if (ap < 0) ap = cfg->precision == LG_PREC_BF16X3 ? PREC_F16 : cfg->precision;
+    if (ap < 0) ap = prec_is_split(cfg->precision) ? PREC_F16 : cfg->precision;
     if (ap != PREC_F32 && ap != PREC_BF16 && ap != PREC_F16) { delete e; return fail(LG_ERR_INVALID, "bad attn_precision"); }
     e->attn_prec = ap;
 #ifdef LG_EXPERIMENTS   // A/B switches of experiment builds (tools/build_variant.sh ... -DLG_EXPERIMENTS); the product reads no environment
@@ -371,7 +378,7 @@ int lg_engine_finalize_weights(lg_engine* e) {
     const int L = e->cfg.n_layers, D = 256, Din = e->cfg.input_dim, prec = e->cfg.precision;
     const int pos_dim = 2 + 2 * (e->cfg.add_scale_ori ? 1 : 0);
     const size_t es = elem_size(prec);
-    const bool split = prec == PREC_BF16X3;
+    const bool split = prec_is_split(prec);
     // ---- size the weight arena
     size_t total = 0;
     auto addw = [&](size_t elems) { total = ((total + 255) & ~size_t(255)) + elems * es; if (split) total = ((total + 255) & ~size_t(255)) + elems * es; };
@@ -437,7 +444,7 @@ int lg_engine_finalize_weights(lg_engine* e) {
                 pb[dst] = b->data[src];
             }
             TRY(upload_packed(prec, pw.data(), pw.size(), e->w_sqkv, (size_t)i * 768 * D));
-            TRY(upload_fragment_packed(prec, std::vector<double>(pw.begin(), pw.end()), 768, D, e->w_sqkv_p + (size_t)i * sqkv_layer, prec == PREC_BF16X3));
+            TRY(upload_fragment_packed(prec, std::vector<double>(pw.begin(), pw.end()), 768, D, e->w_sqkv_p + (size_t)i * sqkv_layer, prec_is_split(prec)));
             TRY(up_f32(e->b_sqkv + (size_t)i * 768, pb.data(), 768));
         }
         {
@@ -491,7 +498,7 @@ int lg_engine_finalize_weights(lg_engine* e) {
             std::memcpy(pw.data() + (size_t)D * D, wv->data.data(), (size_t)D * D * 4);
             std::memcpy(pb.data(), bq->data.data(), D * 4); std::memcpy(pb.data() + D, bv->data.data(), D * 4);
             TRY(upload_packed(prec, pw.data(), pw.size(), e->w_cqkv, (size_t)i * 512 * D));
-            TRY(upload_fragment_packed(prec, std::vector<double>(pw.begin(), pw.end()), 512, D, e->w_cqkv_p + (size_t)i * cqkv_layer, prec == PREC_BF16X3));
+            TRY(upload_fragment_packed(prec, std::vector<double>(pw.begin(), pw.end()), 512, D, e->w_cqkv_p + (size_t)i * cqkv_layer, prec_is_split(prec)));
             TRY(up_f32(e->b_cqkv + (size_t)i * 512, pb.data(), 512));
             TRY(upload_packed(prec, wo->data.data(), (size_t)D * D, e->w_cout, (size_t)i * D * D));
             TRY(up_f32(e->b_cout + (size_t)i * D, bo->data.data(), D));

@@ -23,6 +23,7 @@ template <> struct PT<PREC_F32> { typedef TagF32 Tag; static constexpr int KE = 
 template <> struct PT<PREC_BF16> { typedef TagBF16 Tag; static constexpr int KE = 64, NPART = 1; };
 template <> struct PT<PREC_F16> { typedef TagF16 Tag; static constexpr int KE = 64, NPART = 1; };
 template <> struct PT<PREC_BF16X3> { typedef TagBF16 Tag; static constexpr int KE = 64, NPART = 2; };
+template <> struct PT<PREC_F16X3> { typedef TagF16 Tag; static constexpr int KE = 64, NPART = 2; };
 
 // Register image of one fp32-sourced operand tile slice owned by a thread: 4 chunks.
 template <int PREC> struct F32Stage {
@@ -44,9 +45,9 @@ template <int PREC> struct F32Stage {
             const int off = lds_off<128>(row, slot);
             if constexpr (PREC == PREC_F32) {
                 *reinterpret_cast<f32x4*>(part0 + off) = v[i][0];
-            } else if constexpr (PREC == PREC_BF16X3) {
+            } else if constexpr (PT<PREC>::NPART == 2) {
                 u32x4 hi, lo;
-                split8_bf16(v[i][0], v[i][1], hi, lo);
+                split8<typename PT<PREC>::Tag>(v[i][0], v[i][1], hi, lo);
                 *reinterpret_cast<u32x4*>(part0 + off) = hi;
                 *reinterpret_cast<u32x4*>(part0 + TILE_BYTES + off) = lo;
             } else {
@@ -311,6 +312,7 @@ hipError_t launch_gemm(int prec, int epi, int attn_prec, const GemmArgs& a, hipS
         case PREC_BF16: return launch_prec<PREC_BF16>(epi, attn_prec, a, s);
         case PREC_F16: return launch_prec<PREC_F16>(epi, attn_prec, a, s);
         case PREC_BF16X3: return launch_prec<PREC_BF16X3>(epi, attn_prec, a, s);
+        case PREC_F16X3: return launch_prec<PREC_F16X3>(epi, attn_prec, a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -333,6 +335,7 @@ hipError_t launch_sim(int prec, const SimArgs& a, hipStream_t s) {
         case PREC_BF16: return launch_sim_prec<PREC_BF16>(a, s);
         case PREC_F16: return launch_sim_prec<PREC_F16>(a, s);
         case PREC_BF16X3: return launch_sim_prec<PREC_BF16X3>(a, s);
+        case PREC_F16X3: return launch_sim_prec<PREC_F16X3>(a, s);
     }
     return hipErrorInvalidValue;
 }

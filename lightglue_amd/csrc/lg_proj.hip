@@ -83,7 +83,7 @@ hipError_t launch_proj(int prec, int attn_prec, const ProjArgs& a, hipStream_t s
         case PREC_F32: return launch_proj_p<PREC_F32>(attn_prec, a, s);
         case PREC_BF16: return launch_proj_p<PREC_BF16>(attn_prec, a, s);
         case PREC_F16: return launch_proj_p<PREC_F16>(attn_prec, a, s);
-        case PREC_BF16X3: return launch_proj_p<PREC_QKV_F16W2>(attn_prec, a, s);   // f16 activations x split-f16 weights (lg_proj_body.h)
+        case PREC_BF16X3: case PREC_F16X3: return launch_proj_p<PREC_QKV_F16W2>(attn_prec, a, s);   // f16 activations x split-f16 weights (lg_proj_body.h)
     }
     return hipErrorInvalidValue;
 }

@@ -54,6 +54,7 @@ template <> struct TT<PREC_F32> { typedef TagF32 Tag; static constexpr int KE = 
 template <> struct TT<PREC_BF16> { typedef TagBF16 Tag; static constexpr int KE = 64, NPART = 1; };
 template <> struct TT<PREC_F16> { typedef TagF16 Tag; static constexpr int KE = 64, NPART = 1; };
 template <> struct TT<PREC_BF16X3> { typedef TagBF16 Tag; static constexpr int KE = 64, NPART = 2; };
+template <> struct TT<PREC_F16X3> { typedef TagF16 Tag; static constexpr int KE = 64, NPART = 2; };
 
 // LDS map (bytes):  [0, G_BYTES) g tiles  — aliased during phase A by the two staging buffers
 //                   [G_BYTES, +RED_BYTES) cross-wave reduction scratch
@@ -194,9 +195,9 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             char* tile = smem + (hf * HS + i * SPR + sst) * TILE;   // planes: p * G_PLANE
             if constexpr (PREC == PREC_F32) {
                 *reinterpret_cast<f32x4*>(tile + off) = hreg[i][0];
-            } else if constexpr (PREC == PREC_BF16X3) {
+            } else if constexpr (NPART == 2) {
                 u32x4 hi, lo;
-                split8_bf16(hreg[i][0], hreg[i][1], hi, lo);
+                split8<Tag>(hreg[i][0], hreg[i][1], hi, lo);
                 *reinterpret_cast<u32x4*>(tile + off) = hi;
                 *reinterpret_cast<u32x4*>(tile + G_PLANE + off) = lo;
             } else {
@@ -330,6 +331,10 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
                     const float h0 = bf16_round(v01[0]), h1 = bf16_round(v01[1]), h2 = bf16_round(v23[0]), h3 = bf16_round(v23[1]);
                     *reinterpret_cast<u32x2*>(dst) = u32x2{pack2_bf16(h0, h1), pack2_bf16(h2, h3)};
                     *reinterpret_cast<u32x2*>(dst + G_PLANE) = u32x2{pack2_bf16(v01[0] - h0, v01[1] - h1), pack2_bf16(v23[0] - h2, v23[1] - h3)};
+                } else if constexpr (PREC == PREC_F16X3) {
+                    const float h0 = (float)(f16_t)v01[0], h1 = (float)(f16_t)v01[1], h2 = (float)(f16_t)v23[0], h3 = (float)(f16_t)v23[1];
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{pack2_f16(h0, h1), pack2_f16(h2, h3)};
+                    *reinterpret_cast<u32x2*>(dst + G_PLANE) = u32x2{pack2_f16(v01[0] - h0, v01[1] - h1), pack2_f16(v23[0] - h2, v23[1] - h3)};
                 } else {
                     *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<Tag>(v01[0], v01[1]), pack2<Tag>(v23[0], v23[1])};
                 }
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             if constexpr (NEXT != 0) {
                 static_assert(EPC == 8, "fused next projection: 16-bit operands only");
                 char* dst = smem + (col >> 6) * TILE + lds_off<128>(row, (col & 63) >> 3) + (col & 7) * 2;
-                if constexpr (PREC == PREC_BF16X3) {   // the projection takes ONE f16 plane (PREC_QKV_F16W2, lg_proj_body.h)
+                if constexpr (NPART == 2) {   // split precisions: the projection takes ONE f16 plane (PREC_QKV_F16W2, lg_proj_body.h)
                     *reinterpret_cast<u32x2*>(dst) = u32x2{pack2_f16(xn[0], xn[1]), pack2_f16(xn[2], xn[3])};
                 } else {
                     *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<Tag>(xn[0], xn[1]), pack2<Tag>(xn[2], xn[3])};
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         }
     }
     stamp(5);
-    if constexpr (NEXT != 0) proj_compute<(PREC == PREC_BF16X3 ? PREC_QKV_F16W2 : PREC), TA, NEXT == 1 ? 3 : 2, 2, G_PLANE, MT>(a.next, t, smem, 8);
+    if constexpr (NEXT != 0) proj_compute<(prec_is_split(PREC) ? PREC_QKV_F16W2 : PREC), TA, NEXT == 1 ? 3 : 2, 2, G_PLANE, MT>(a.next, t, smem, 8);
     if (a.dbg && lane == 0)   // wall clock at the end + where the workgroup ran (HW_ID, XCC_ID)
         a.dbg[((long long)blockIdx.x * 8 + w) * 8 + 7] = (wall_clock64() & ((1LL << 44) - 1)) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFF00) << 40) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 44);
 }
@@ -484,7 +489,7 @@ template <int PREC, class TA> static hipError_t launch_tail_next(const TailArgs&
 
 // the fused next projection exists for the 16-bit operand / attention combinations the engine runs by default
 bool launch_tail_supports_next(int prec, int attn_prec) {
-    return (prec == PREC_BF16X3 && attn_prec == PREC_F16) || (prec == PREC_BF16 && attn_prec == PREC_BF16) ||
+    return (prec_is_split(prec) && attn_prec == PREC_F16) || (prec == PREC_BF16 && attn_prec == PREC_BF16) ||
            (prec == PREC_F16 && attn_prec == PREC_F16);
 }
 
@@ -495,6 +500,7 @@ hipError_t launch_tail(int prec, int attn_prec, const TailArgs& a, hipStream_t s
         case PREC_BF16: return launch_tail_next<PREC_BF16, bf16_t>(a, s);
         case PREC_F16: return launch_tail_next<PREC_F16, f16_t>(a, s);
         case PREC_BF16X3: return launch_tail_next<PREC_BF16X3, f16_t>(a, s);
+        case PREC_F16X3: return launch_tail_next<PREC_F16X3, f16_t>(a, s);
     }
     return hipErrorInvalidValue;
 }

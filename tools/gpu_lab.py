@@ -50,6 +50,7 @@ def main():
                 stop = o["stop"] if not torch.is_tensor(o["stop"]) else o["stop"].cpu().tolist()
                 rec = dict(idx_mismatch0=int((m0 != gold["matches0"]).sum()), idx_mismatch1=int((o["matches1"].cpu().numpy() != gold["matches1"]).sum()),
                            max_dscore=float(np.abs(s0 - gold["matching_scores0"]).max()) if s0.size else 0.0,
+                           rms_dscore=float(np.sqrt(np.mean((s0 - gold["matching_scores0"]) ** 2))) if s0.size else 0.0,
                            n=int((gold["matches0"] > -1).sum()), got_n=int((m0 > -1).sum()), stop=stop, ref_stop=gold["stop"].tolist(),
                            prune_mismatch=int((o["prune0"].cpu().numpy().astype(np.float32) != gold["prune0"]).sum()))
             except Exception:

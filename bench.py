@@ -6,7 +6,7 @@ and early-stop OFF, batch 32 pairs per GPU, inputs resident in HBM, synthetic da
 One "step" = one LightGlue.forward over one batch of 32 pairs (the whole reference forward: layers,
 log-assignment, match filtering and the ragged match lists).
 
-    python bench.py [--gpus N --steps K --warmup W] [--precision bf16x3|bf16|fp16|fp32]
+    python bench.py [--gpus N --steps K --warmup W] [--precision bf16x3|f16x3|bf16|fp16|fp32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -223,7 +223,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp16", "fp32"])
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f16x3", "bf16", "fp16", "fp32"])   # f16x3: opt-in, see DESIGN.md §1
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per step")
     ap.add_argument("--kpts", type=int, default=N_KPTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -378,7 +378,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"bf16x3": "bf16", "bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.precision],
+            "dtype": {"bf16x3": "bf16", "f16x3": "f16", "bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"SuperPoint-dim 256-d descriptors, N=M={n}, 9 layers, pruning/early-stop OFF, batch={B} pairs per GPU, "
                                    f"seeded random weights (recipe A), precision={args.precision}"
@@ -414,7 +414,7 @@ def main():
         }
         # match-index parity of the batch that was just timed (rank 0's pairs): against the reference's own fixture for the
         # first 4 pairs and against the oracle on the pairs the CPU leg runs anyway
-        default_weights = args.precision in ("bf16x3", "fp32")
+        default_weights = args.precision in ("bf16x3", "f16x3", "fp32")
         res["parity"] = golden_parity(out, n, B) if default_weights else None
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"], res["parity_oracle"] = cpu_baseline(sd, n, m, gpu_out=out)

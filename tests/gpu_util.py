@@ -18,7 +18,7 @@ def make_model(sd, precision, **conf):
     return model
 
 
-ATTN_DTYPE = {"fp32": "f32", "bf16": "bf16", "fp16": "f16", "bf16x3": "f16"}
+ATTN_DTYPE = {"fp32": "f32", "bf16": "bf16", "fp16": "f16", "bf16x3": "f16", "f16x3": "f16"}
 
 
 def read_attn_buf(model, name):

@@ -103,6 +103,11 @@ struct lg_engine {
     char *w_stail_cat = nullptr, *w_stail_2 = nullptr, *w_ctail_cat = nullptr, *w_ctail_2 = nullptr;
     float *b_scat = nullptr, *b_ccat = nullptr;
     size_t tail_cat_layer_bytes = 0, tail_2_layer_bytes = 0;
+#ifdef LG_EXPERIMENTS
+    // ctx-half experiment (lg_tail.hip LG_TAIL_CTX_FP6, precision f16x3): per (block type, layer) the ctx half of Wcat as f16
+    // fragments in block-consecutive k order + hi scales (CTX16_BYTES) and fp6 lo records (CTX6_BYTES); own allocation
+    char *w_ctx16 = nullptr, *w_ctx6 = nullptr;
+#endif
     char *w_sqkv_p = nullptr, *w_cqkv_p = nullptr;   // fragment-packed projection weights (lg_proj.hip)
     size_t sqkv_layer_bytes = 0, cqkv_layer_bytes = 0;
     bool attn_dma = true;   // option "attn_dma": LDS-DMA attention kernel (16-bit operands, 32 rows per wave)
@@ -192,6 +197,67 @@ int upload_fragment_packed(int prec, const std::vector<double>& W, int rows, int
     HIPCHK(hipMemcpy(dst, buf.data(), buf.size(), hipMemcpyHostToDevice));
     return LG_OK;
 }
+
+#ifdef LG_EXPERIMENTS
+constexpr size_t CTX16_FRAG_BYTES = (size_t)32 * 2 * 4 * 64 * 16, CTX16_BYTES = CTX16_FRAG_BYTES + (size_t)32 * 2 * 64 * 4, CTX6_BYTES = (size_t)32 * 2 * 64 * 32;
+// fp6 e2m3 code (sign, 2 exponent bits with bias 1, 3 mantissa bits; subnormal step 0.125) of v, round to nearest even, saturating at 7.5
+unsigned fp6_e2m3_code(float v) {
+    const unsigned sign = std::signbit(v) ? 32u : 0u;
+    const float a = std::fabs(v);
+    if (!(a < 7.75f)) return sign | 31u;                       // saturate (also NaN)
+    if (a < 1.0f) {                                            // subnormal range, step 0.125; 8 steps = 1.0 = (e 1, m 0)
+        const int m = (int)std::nearbyint(a * 8.0f);
+        return sign | (m == 8 ? 8u : (unsigned)m);
+    }
+    int e = a < 2.0f ? 0 : (a < 4.0f ? 1 : 2);                // value = (1 + m/8) 2^e
+    int m = (int)std::nearbyint(std::ldexp(a, 3 - e));         // 8 .. 16
+    if (m == 16) { m = 8; ++e; }
+    if (e > 2) return sign | 31u;
+    return sign | ((unsigned)(e + 1) << 3) | (unsigned)(m - 8);
+}
+// smallest E8M0 byte with amax / 2^(byte - 127) <= 7.5 — the same rule as the kernel's e8m0_for
+int e8m0_for_host(float amax) {
+    if (amax == 0.f) return 127;
+    const float t = amax * (16.f / 15.f);
+    uint32_t u; std::memcpy(&u, &t, 4);
+    const int e = (int)((u >> 23) & 0xFF) - 2;
+    return e < 1 ? 1 : e;
+}
+// one MX block of 32 weights -> f16 hi halves, the hi block's scale, 24 bytes of fp6 lo codes (slot i at bits [6i, 6i+6)) and their scale
+void split_block_fp6(const float* v, uint16_t* h16, int& sh, uint32_t* lo6, int& sl) {
+    float hf[32], l[32], ah = 0.f, al = 0.f;
+    for (int i = 0; i < 32; ++i) {
+        h16[i] = f32_to_f16(v[i]); hf[i] = f16_to_f32(h16[i]); l[i] = v[i] - hf[i];
+        ah = std::fmax(ah, std::fabs(hf[i])); al = std::fmax(al, std::fabs(l[i]));
+    }
+    sh = e8m0_for_host(ah); sl = e8m0_for_host(al);
+    for (int i = 0; i < 6; ++i) lo6[i] = 0;
+    for (int i = 0; i < 32; ++i) {
+        const uint64_t code = fp6_e2m3_code(std::ldexp(l[i], 127 - sl));
+        const int bit = 6 * i, wd = bit >> 5, sft = bit & 31;
+        lo6[wd] |= (uint32_t)(code << sft);
+        if (sft > 26) lo6[wd + 1] |= (uint32_t)(code >> (32 - sft));
+    }
+}
+// the ctx half (columns 256..511) of a folded [512][512] ffn.0 matrix in the layout lg_tail.hip's ctx-half experiment reads
+void pack_ctx6(const std::vector<double>& cat, std::vector<char>& w16, std::vector<char>& w6) {
+    w16.assign(CTX16_BYTES, 0); w6.assign(CTX6_BYTES, 0);
+    for (int nt = 0; nt < 32; ++nt)
+        for (int c = 0; c < 2; ++c)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int lr = lane & 15, g = lane >> 4;
+                float v[32]; uint16_t h16[32]; uint32_t lo6[6]; int sh, sl;
+                for (int i = 0; i < 32; ++i) v[i] = (float)cat[(size_t)(nt * 16 + lr) * 512 + 256 + 128 * c + 32 * g + i];
+                split_block_fp6(v, h16, sh, lo6, sl);
+                const size_t base = (size_t)nt * 2 + c;
+                for (int q = 0; q < 4; ++q) std::memcpy(&w16[((base * 4 + q) * 64 + lane) * 16], &h16[8 * q], 16);
+                const uint32_t shd = (uint32_t)sh * 0x01010101u, sld = (uint32_t)sl * 0x01010101u;
+                std::memcpy(&w16[CTX16_FRAG_BYTES + (base * 64 + lane) * 4], &shd, 4);
+                uint32_t rec[8] = {lo6[0], lo6[1], lo6[2], lo6[3], lo6[4], lo6[5], sld, 0u};
+                std::memcpy(&w6[(base * 64 + lane) * 32], rec, 32);
+            }
+}
+#endif
 
 const HostTensor* find(const lg_engine* e, const std::string& name, std::initializer_list<int64_t> shape, std::string& err) {
     auto it = e->staged.find(name);
@@ -359,6 +425,10 @@ void lg_engine_destroy(lg_engine* e) {
     for (auto& sp : e->prof_pool) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     if (e->ws) (void)hipFree(e->ws);
     if (e->w_arena) (void)hipFree(e->w_arena);
+#ifdef LG_EXPERIMENTS
+    if (e->w_ctx16) (void)hipFree(e->w_ctx16);
+    if (e->w_ctx6) (void)hipFree(e->w_ctx6);
+#endif
     delete e;
 }
 
@@ -486,6 +556,15 @@ int lg_engine_finalize_weights(lg_engine* e) {
             }
             for (size_t q = 0; q < w2d.size(); ++q) w2d[q] = w3->data[q];
             TRY(upload_fragment_packed(prec, cat, 512, 512, (blk ? e->w_ctail_cat : e->w_stail_cat) + (size_t)i * cat_layer));
+#ifdef LG_EXPERIMENTS
+            if (prec == PREC_F16X3) {
+                if (!e->w_ctx16) { HIPCHK(hipMalloc(&e->w_ctx16, 2 * (size_t)L * CTX16_BYTES)); HIPCHK(hipMalloc(&e->w_ctx6, 2 * (size_t)L * CTX6_BYTES)); }
+                std::vector<char> w16, w6;
+                pack_ctx6(cat, w16, w6);
+                HIPCHK(hipMemcpy(e->w_ctx16 + ((size_t)blk * L + i) * CTX16_BYTES, w16.data(), CTX16_BYTES, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->w_ctx6 + ((size_t)blk * L + i) * CTX6_BYTES, w6.data(), CTX6_BYTES, hipMemcpyHostToDevice));
+            }
+#endif
             TRY(upload_fragment_packed(prec, w2d, 256, 512, (blk ? e->w_ctail_2 : e->w_stail_2) + (size_t)i * w2_layer));
             TRY(up_f32((blk ? e->b_ccat : e->b_scat) + (size_t)i * 512, bc.data(), 512));
         }
@@ -828,6 +907,9 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 ta.gamma = (blk ? e->ln_c_g : e->ln_s_g) + (size_t)i * 512; ta.beta = (blk ? e->ln_c_b : e->ln_s_b) + (size_t)i * 512;
                 ta.W2 = (blk ? e->w_ctail_2 : e->w_stail_2) + (size_t)i * e->tail_2_layer_bytes;
                 ta.b2 = (blk ? e->b_cf2 : e->b_sf2) + (size_t)i * D;
+#ifdef LG_EXPERIMENTS
+                if (e->w_ctx16) { ta.Wc16 = e->w_ctx16 + ((size_t)blk * L + i) * CTX16_BYTES; ta.Wc6 = e->w_ctx6 + ((size_t)blk * L + i) * CTX6_BYTES; }
+#endif
                 ta.dbg = e->tail_timing == 1 ? e->TAILDBG : nullptr;
                 ta.row_tiles = e->tail_row_tiles ? e->tail_row_tiles : tail_row_tiles_for(R);
                 // Across a layer boundary the fusion is valid whenever no row can MOVE in between: early stop alone only
@@ -948,5 +1030,26 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
 #undef TRY
     return LG_OK;
 }
+
+#ifdef LG_EXPERIMENTS
+// experiment builds only (not in include/lightglue_amd.h): the host-side MX-block split of the ctx-half experiment, for a CPU test
+// against the numpy emulation (tests/test_fp6_packing.py).  v[32] -> h16[32] (f16 bits), *sh, lo6[6] (fp6 codes, slot i at bits [6i, 6i+6)), *sl
+int lg_debug_split_block_fp6(const float* v, uint16_t* h16, int32_t* sh, uint32_t* lo6, int32_t* sl) {
+    int a, b;
+    split_block_fp6(v, h16, a, lo6, b);
+    *sh = a; *sl = b;
+    return LG_OK;
+}
+// cat [512][512] (row-major, columns 256..511 = the ctx half) -> the two device buffers, on the host (sizes via the first call with null outputs)
+int lg_debug_pack_ctx6(const double* cat, char* w16, char* w6, int64_t* w16_bytes, int64_t* w6_bytes) {
+    if (w16_bytes) *w16_bytes = (int64_t)CTX16_BYTES;
+    if (w6_bytes) *w6_bytes = (int64_t)CTX6_BYTES;
+    if (!cat || !w16 || !w6) return LG_OK;
+    std::vector<char> a, b;
+    pack_ctx6(std::vector<double>(cat, cat + (size_t)512 * 512), a, b);
+    std::memcpy(w16, a.data(), a.size()); std::memcpy(w6, b.data(), b.size());
+    return LG_OK;
+}
+#endif
 
 }  // extern "C"

@@ -70,6 +70,11 @@ struct TailArgs {
     // optional: the NEXT block's q/k/v projection, run on the x tile this kernel has just produced (next.W == nullptr:
     // none).  next.X is unused; supported for 16-bit operand / attention precisions (launch_tail_supports_next).
     ProjArgs next;
+#ifdef LG_EXPERIMENTS
+    // ctx-half experiment (lg_tail.hip LG_TAIL_CTX_FP6, precision f16x3): the ctx half of Wcat re-packed as f16 fragments in the
+    // block-consecutive k order ([n-tile 32][c 2][q 4][lane 64][16 B]) and fp6 lo records ([n-tile 32][c 2][lane 64][32 B])
+    const void* Wc16; const void* Wc6;
+#endif
 };
 bool launch_tail_supports_next(int prec, int attn_prec);
 hipError_t launch_tail_rows128(const TailArgs& a, hipStream_t s);   // experiment builds: 128 rows per workgroup, PREC_BF16X3 + f16 attention only (lg_tail128.hip)

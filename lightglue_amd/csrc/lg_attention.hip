@@ -19,6 +19,15 @@
 // The S matrix never touches HBM.  Softmax runs in fp32 with exp2 and a folded log2(e)/sqrt(64).
 #include "lg_kernels.h"
 
+// Experiment (tools/build_variant.sh fold -DLG_ATTN_FOLD=1; the product build leaves it at 0 and its machine code is unchanged):
+// q and k leave the projection pre-multiplied by sqrt(log2(e) / 8) (lg_proj_body.h, as the reference's own CPU path splits its scale
+// over both operands, lightglue.py:215), and the LDS-DMA kernel starts every score accumulator at -m_run instead of 0, so that
+// exp2 applies to the MFMA result directly: 32 v_fma_f32 fewer per 64-key tile in a loop that is bound by VALU issue.
+// Not bit-identical to the default (q, k are rounded to f16 after the scaling instead of before) — same error class.
+#ifndef LG_ATTN_FOLD
+#define LG_ATTN_FOLD 0
+#endif
+
 namespace lg {
 
 constexpr int ABK = 64, ATHREADS = 256;   // query rows per workgroup = 64 * QT (QT 16-row query tiles per wave, 4 waves)
@@ -196,7 +205,11 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
             const float t4 = vmax3(s[3][qt][0], s[3][qt][1], s[3][qt][2]);
             float mx = vmax2(vmax3(t0, t1, t2), vmax3(t3, t4, s[3][qt][3]));
             mx = xor32_max(xor16_max(mx));   // the 4 lane groups of a query column, no LDS round trip
+#if LG_ATTN_FOLD
+            m_new[qt] = vmax2(m_run[qt], mx);                    // (q, k carry the scale)
+#else
             m_new[qt] = vmax2(m_run[qt], mx * a.scale_log2e);   // finite: every tile holds >= 1 live key (scale > 0)
+#endif
             grew = grew || (m_new[qt] > m_run[qt] + 8.f);
         }
         // Deferred rescale (guide T13): keep the stale running maximum while no row's maximum grew by more than 2^8
@@ -222,7 +235,11 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
             // fine).  Packed f32 ops (v_pk_fma_f32 / v_pk_add_f32) are cheaper on their own but barely co-issue with another
             // wave's MFMAs on the SIMD (tools/ubench/mfma_valu_overlap.hip: 24 % overlap vs 79 % for v_fma_f32), and this
             // kernel lives on that overlap.  Two partial sums keep the add chain short.
+#if LG_ATTN_FOLD
+            const float sc = 1.0f, nm = -m_run[qt];
+#else
             const float sc = a.scale_log2e, nm = -m_run[qt];
+#endif
             float rs0 = 0.f, rs1 = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
@@ -395,7 +412,11 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_dma_kernel(AttnArgs a) {
     float m_run[QT], l_run[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
+#if LG_ATTN_FOLD
+        m_run[qt] = 0.f; l_run[qt] = 0.f;          // finite: the accumulators start at -m_run; the first tile always re-bases (below)
+#else
         m_run[qt] = -INFINITY; l_run[qt] = 0.f;
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -438,7 +459,11 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_dma_kernel(AttnArgs a) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
+#if LG_ATTN_FOLD
+            for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{-m_run[qt], -m_run[qt], -m_run[qt], -m_run[qt]};   // scores arrive as s - m_run (the first MFMA of a chain reads this tuple as its C operand)
+#else
             for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
@@ -458,6 +483,47 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_dma_kernel(AttnArgs a) {
                     for (int r = 0; r < 4; ++r)
                         if (kv0 + 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r >= kvlen) s[kt][qt][r] = -INFINITY;
         }
+#if LG_ATTN_FOLD
+        // s holds d = score - m_run.  Row maximum of d; re-base when it exceeds 8 (deferred rescale: p <= 2^8 otherwise) and
+        // always on the first tile (m_run = 0 there is arbitrary; the re-base may go DOWN, so alpha is not used for it: l = o = 0)
+        float dmax[QT];
+        bool grew = tile == 0;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const float t0 = vmax3(s[0][qt][0], s[0][qt][1], s[0][qt][2]), t1 = vmax3(s[0][qt][3], s[1][qt][0], s[1][qt][1]);
+            const float t2 = vmax3(s[1][qt][2], s[1][qt][3], s[2][qt][0]), t3 = vmax3(s[2][qt][1], s[2][qt][2], s[2][qt][3]);
+            const float t4 = vmax3(s[3][qt][0], s[3][qt][1], s[3][qt][2]);
+            float mx = vmax2(vmax3(t0, t1, t2), vmax3(t3, t4, s[3][qt][3]));
+            dmax[qt] = xor32_max(xor16_max(mx));              // finite: every tile holds >= 1 live key
+            grew = grew || (dmax[qt] > 8.f);
+        }
+        if (__any(grew)) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const float shift = tile == 0 ? dmax[qt] : vmax2(dmax[qt], 0.f);
+                const float alpha = tile == 0 ? 0.f : __builtin_amdgcn_exp2f(-shift);
+                l_run[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt][qt] *= alpha;
+                m_run[qt] += shift;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) s[kt][qt] -= shift;
+            }
+        }
+        ATT_TICK(3);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float rs0 = 0.f, rs1 = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const float p0 = __builtin_amdgcn_exp2f(s[kt][qt][0]), p1 = __builtin_amdgcn_exp2f(s[kt][qt][1]);
+                const float p2 = __builtin_amdgcn_exp2f(s[kt][qt][2]), p3 = __builtin_amdgcn_exp2f(s[kt][qt][3]);
+                s[kt][qt][0] = p0; s[kt][qt][1] = p1; s[kt][qt][2] = p2; s[kt][qt][3] = p3;
+                rs0 += p0 + p2; rs1 += p1 + p3;
+            }
+            l_run[qt] += rs0 + rs1;
+        }
+#else
         float m_new[QT];
         bool grew = false;
 #pragma unroll
@@ -494,6 +560,7 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_dma_kernel(AttnArgs a) {
             }
             l_run[qt] += rs0 + rs1;
         }
+#endif
         ATT_TICK(4);
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp) {

@@ -616,6 +616,9 @@ int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
 #else
     if (std::strcmp(key, "tail_variant") == 0) return value == 0 ? LG_OK : fail(LG_ERR_INVALID, "tail_variant: the streaming tail variants are experiment builds only (-DLG_EXPERIMENTS)");
 #endif
+#if defined(LG_ATTN_FOLD) && LG_ATTN_FOLD   // experiment build: only the fragment-packed projection pre-scales q and k (lg_proj_body.h)
+    if (std::strcmp(key, "fused_proj") == 0) { if (!value) return fail(LG_ERR_INVALID, "fused_proj = 0 is not available in LG_ATTN_FOLD builds"); return LG_OK; }
+#endif
     if (std::strcmp(key, "fused_proj") == 0) { e->fused_proj = value != 0; return LG_OK; }
 #ifdef LG_EXPERIMENTS
     if (std::strcmp(key, "tail_rows") == 0) { if (value != 0 && value != 64 && value != 128) return fail(LG_ERR_INVALID, "tail_rows must be 0, 64 or 128"); e->tail_rows = value; return LG_OK; }

@@ -10,6 +10,9 @@
 namespace lg {
 
 constexpr int PBM = 64, PTHREADS = 512;
+#ifndef LG_ATTN_FOLD
+#define LG_ATTN_FOLD 0   // experiment, see lg_attention.hip: q and k leave the projection pre-multiplied by the square root of the score scale
+#endif
 
 // Operand scheme of the projection.  NPART = weight planes, APART = activation planes.
 // PREC_QKV_F16W2 is what the default precision ("bf16x3") uses for the q/k/v projections: the activation tile as ONE f16
@@ -163,6 +166,9 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
                     v[0] = u[0] * c[0] - u[1] * sn[0]; v[1] = u[1] * c[0] + u[0] * sn[0];
                     v[2] = u[2] * c[1] - u[3] * sn[1]; v[3] = u[3] * c[1] + u[2] * sn[1];
                 }
+#if LG_ATTN_FOLD
+                v *= 0.42466090014400953f;                // sqrt(log2(e) / sqrt(64)): the attention's score scale, split over q and k (lg_attention.hip LG_ATTN_FOLD)
+#endif
                 ta4 o = {pj_cvt<TA>(v[0]), pj_cvt<TA>(v[1]), pj_cvt<TA>(v[2]), pj_cvt<TA>(v[3])};
                 *reinterpret_cast<ta4*>(base + ((long long)head * R + row) * 64 + d0 + 4 * g) = o;
             }

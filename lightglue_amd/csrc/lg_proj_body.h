@@ -10,6 +10,9 @@
 namespace lg {
 
 constexpr int PBM = 64, PTHREADS = 512;
+#ifndef LG_PROJ_EPI_PREFETCH
+#define LG_PROJ_EPI_PREFETCH 0   // scheduling experiment (same arithmetic): 1 = issue the epilogue's bias / rotary loads before the MFMA loop (+60 live VGPRs, no exposed L2 round trip at the head of the two epilogues)
+#endif
 #ifndef LG_ATTN_FOLD
 #define LG_ATTN_FOLD 0   // experiment, see lg_attention.hip: q and k leave the projection pre-multiplied by the square root of the score scale
 #endif
@@ -90,6 +93,30 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NTP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if LG_PROJ_EPI_PREFETCH   // experiment: the epilogue's operands (bias, rotary tables) are fetched BEFORE the MFMA loop instead of after it
+    typedef TA ta4 __attribute__((ext_vector_type(4)));
+    f32x4 b4[NTP]; float bv[NTP];
+    f32x2 c2[NTP][MT], s2[NTP][MT];
+#pragma unroll
+    for (int j = 0; j < NTP; ++j) {
+        constexpr int dummy = 0; (void)dummy;
+        const int jj = PASS * NTP + j;
+        const int col0 = (w + 8 * jj) * 16, d0 = col0 & 63;
+        if ((jj >> 1) < N_QK) {
+            b4[j] = *reinterpret_cast<const f32x4*>(a.bias + col0 + 4 * g);
+            if constexpr (NTP == 3) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const long long row = t.grow0 + mt * 16 + lr;
+                    c2[j][mt] = *reinterpret_cast<const f32x2*>(a.cosb + row * 32 + (d0 >> 1) + 2 * g);
+                    s2[j][mt] = *reinterpret_cast<const f32x2*>(a.sinb + row * 32 + (d0 >> 1) + 2 * g);
+                }
+            }
+        } else {
+            bv[j] = a.bias[col0 + lr];
+        }
+    }
+#endif
 #pragma unroll 1
     for (int c0 = 0; c0 < NKC; c0 += NBUF) {
 #pragma unroll
@@ -126,6 +153,7 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
     // ---- epilogue of the pass, straight from the accumulators.  All loads (bias, rotary tables) are issued BEFORE the first
     // store: the compiler cannot prove that q/k/v do not alias the tables, so a load placed after a store stays there and
     // every (tile, 16-row tile) iteration would expose one full L2 round trip (measured: 14k cycles for 12 iterations).
+#if !LG_PROJ_EPI_PREFETCH
     typedef TA ta4 __attribute__((ext_vector_type(4)));
     f32x4 b4[NTP]; float bv[NTP];
     f32x2 c2[NTP][MT], s2[NTP][MT];
@@ -148,6 +176,7 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
             bv[j] = a.bias[col0 + lr];
         }
     }
+#endif
 #pragma unroll
     for (int j = 0; j < NTP; ++j) {
         constexpr int dummy = 0; (void)dummy;

@@ -61,4 +61,15 @@ def test_argument_validation_without_gpu():
     io = _cabi.LgForwardIO()
     io.batch, io.n0, io.n1 = 1, 4, 4
     assert lib.lg_engine_forward(h, ctypes.byref(io), None) == _cabi.LG_ERR_STATE
+    # options: unknown keys and experiment-only switches are refused by the product library, with a message
+    assert lib.lg_engine_set_option(h, b"fused_next", 0) == _cabi.LG_OK
+    assert lib.lg_engine_set_option(h, b"no_such_option", 1) == _cabi.LG_ERR_INVALID and b"no_such_option" in lib.lg_last_error()
+    assert lib.lg_engine_set_option(h, b"tail_variant", 1) == _cabi.LG_ERR_INVALID and b"experiment" in lib.lg_last_error()
     lib.lg_engine_destroy(h)
+    # precision enum: every named mode is accepted, anything past the last one is not
+    for name, val in _cabi.LG_PREC.items():
+        cfg = _cabi.LgConfig(256, 256, 9, 4, 0, 0.95, 0.99, 0.1, -1, val, -1)
+        assert lib.lg_engine_create(ctypes.byref(cfg), ctypes.byref(h)) == _cabi.LG_OK, name
+        lib.lg_engine_destroy(h)
+    cfg = _cabi.LgConfig(256, 256, 9, 4, 0, 0.95, 0.99, 0.1, -1, max(_cabi.LG_PREC.values()) + 1, -1)
+    assert lib.lg_engine_create(ctypes.byref(cfg), ctypes.byref(h)) == _cabi.LG_ERR_INVALID and b"precision" in lib.lg_last_error()

@@ -10,6 +10,9 @@
 namespace lg {
 
 constexpr int PBM = 64, PTHREADS = 512;
+#ifndef LG_PROJ_ABLATE_W
+#define LG_PROJ_ABLATE_W 0       // timing ablation (wrong results): constant weight fragments in the projection's MFMA loop
+#endif
 #ifndef LG_PROJ_EPI_PREFETCH
 #define LG_PROJ_EPI_PREFETCH 0   // scheduling experiment (same arithmetic): 1 = issue the epilogue's bias / rotary loads before the MFMA loop (+60 live VGPRs, no exposed L2 round trip at the head of the two epilogues)
 #endif
@@ -79,6 +82,9 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
         if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8 + stamp_base + slot] = clock64();
     };
     auto wfrag = [&](int p, int nt, int kc) -> u32x4 {
+#if LG_PROJ_ABLATE_W   // TIMING ABLATION ONLY (wrong results): no weight loads at all — is the loop bound by the L2 weight stream?
+        return u32x4{0x3c003c00u + (unsigned)lane, 0x3c003c00u + (unsigned)(nt + kc), 0x3c003c00u + (unsigned)p, 0x3c003c00u};
+#endif
         const char* ptr = static_cast<const char*>(a.W) + (p ? (long long)a.Nout * 256 * (long long)sizeof(typename Tag::elem) : 0);
         return *reinterpret_cast<const u32x4*>(ptr + ((long long)(nt * NKC + kc) * 64 + lane) * 16);
     };

@@ -1,6 +1,6 @@
 #!/bin/bash
 # First GPU call of the next round: everything below was BUILT at the end of round 2 without GPU minutes left.
-# In the build container first:   tools/tail_sched_variants.sh build ; tools/build_variant.sh ctx6 -DLG_EXPERIMENTS -DLG_TAIL_CTX_FP6=1 ; tools/build_variant.sh fold -DLG_ATTN_FOLD=1
+# In the build container first:   tools/tail_sched_variants.sh build ; tools/build_variant.sh ctx6 -DLG_EXPERIMENTS -DLG_TAIL_CTX_FP6=1 ; tools/build_variant.sh fold -DLG_ATTN_FOLD=1 ; tools/build_variant.sh ablw -DLG_PROJ_ABLATE_W=1
 # then:   gpurun --timeout 1500 -- 'bash tools/round3_first_call.sh'        (≈15-20 min of box time; results in gpurun_out/round3/)
 mkdir -p gpurun_out/round3; O=gpurun_out/round3
 export TMPDIR=/tmp
@@ -27,6 +27,7 @@ for round in 1 2; do
   for v in o1 o2 gs o1gs o2gs pe; do [ -f lightglue_amd/liblightglue_amd_sched_$v.so ] && ab lightglue_amd/liblightglue_amd_sched_$v.so; done
   [ -f lightglue_amd/liblightglue_amd_ctx6.so ] && ab lightglue_amd/liblightglue_amd_ctx6.so f16x3
   [ -f lightglue_amd/liblightglue_amd_fold.so ] && ab lightglue_amd/liblightglue_amd_fold.so
+  [ -f lightglue_amd/liblightglue_amd_ablw.so ] && ab lightglue_amd/liblightglue_amd_ablw.so   # TIMING ABLATION (wrong results, parity column meaningless): projection without weight loads
 done 2>&1 | tee $O/ab.log
 # 3. the ctx-half build against the goldens (same gated tests, other library)
 [ -f lightglue_amd/liblightglue_amd_ctx6.so ] && { LIGHTGLUE_AMD_LIB=$PWD/lightglue_amd/liblightglue_amd_ctx6.so LG_TEST_UNVALIDATED=1 timeout 600 python -m pytest tests/test_gpu_unvalidated.py -m gpu -q > $O/ctx6_tests.log 2>&1; tail -3 $O/ctx6_tests.log; }

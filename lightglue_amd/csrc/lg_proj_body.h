@@ -10,6 +10,9 @@
 namespace lg {
 
 constexpr int PBM = 64, PTHREADS = 512;
+#ifndef LG_PROJ_PINGPONG
+#define LG_PROJ_PINGPONG 0       // scheduling experiment (same arithmetic): waves 4..7 run both MFMA loops of the projection before both epilogues
+#endif
 #ifndef LG_PROJ_ABLATE_W
 #define LG_PROJ_ABLATE_W 0       // timing ablation (wrong results): constant weight fragments in the projection's MFMA loop
 #endif
@@ -68,9 +71,15 @@ template <int PREC> struct PJL {   // LDS geometry of the activation tile
 //     [head][64][R] layout (4 consecutive rows of one channel).
 // Nothing is staged through LDS and no barrier follows the MFMA loop (the staged version spent 40 % of the kernel in its two
 // epilogues: LDS write, barrier, LDS read, store, barrier).
+#if LG_PROJ_PINGPONG   // experiment: PART 0 = the whole pass (as the product), 1 = its MFMA loop only, 2 = its epilogue only; accumulators owned by the caller
+template <int PREC, class TA, int NTP, int NPASS, int PASS, int A_PLANE, int MT, int PART>
+__device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, const char* smA, u32x4 (&bf)[PJ<PREC>::NPART == 2 ? 2 : 4][NTP][PJ<PREC>::NPART],
+                                          int stamp_base, f32x4 (&acc)[MT][NTP]) {
+#else
 template <int PREC, class TA, int NTP, int NPASS, int PASS, int A_PLANE, int MT>
 __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, const char* smA, u32x4 (&bf)[PJ<PREC>::NPART == 2 ? 2 : 4][NTP][PJ<PREC>::NPART],
                                           int stamp_base) {
+#endif
     typedef typename PJ<PREC>::Tag Tag;
     constexpr int NPART = PJ<PREC>::NPART, APART = PJ<PREC>::APART;
     constexpr int STAGES = PJL<PREC>::STAGES, NKC = 2 * STAGES, TILE = MT * 16 * 128;   // one plane of one K stage: MT*16 rows x 128 B
@@ -94,7 +103,11 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
 #pragma unroll
             for (int p = 0; p < NPART; ++p) dst[j][p] = wfrag(p, w + 8 * (pass * NTP + j), kc);
     };
+#if LG_PROJ_PINGPONG
+    if constexpr (PART != 2) {
+#else
     f32x4 acc[MT][NTP];
+#endif
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -156,6 +169,10 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
         }
     }
     stamp(2 + 2 * PASS);
+#if LG_PROJ_PINGPONG
+    }
+    if constexpr (PART == 1) return;
+#endif
     // ---- epilogue of the pass, straight from the accumulators.  All loads (bias, rotary tables) are issued BEFORE the first
     // store: the compiler cannot prove that q/k/v do not alias the tables, so a load placed after a store stays there and
     // every (tile, 16-row tile) iteration would expose one full L2 round trip (measured: 14k cycles for 12 iterations).
@@ -240,8 +257,24 @@ __device__ __forceinline__ void proj_compute(const ProjArgs& a, const TileLoc& t
             }
     __syncthreads();   // the activation tile is complete
     if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8 + stamp_base + 1] = clock64();
+#if LG_PROJ_PINGPONG
+    // The two waves of a SIMD (w, w + 4) run the passes in DIFFERENT shapes: waves 0..3 as the product (MFMA loop, epilogue, MFMA loop,
+    // epilogue), waves 4..7 both MFMA loops first and both epilogues after — so that an epilogue (VALU, loads, stores) of one wave
+    // faces an MFMA loop of the other instead of the other's epilogue.  Same arithmetic per wave: bit-identical outputs.
+    f32x4 acc0[MT][NTP], acc1[MT][NTP];
+    if (w >= 4) {
+        proj_pass<PREC, TA, NTP, NPASS, 0, A_PLANE, MT, 1>(a, t, smA, bf, stamp_base, acc0);
+        proj_pass<PREC, TA, NTP, NPASS, 1, A_PLANE, MT, 1>(a, t, smA, bf, stamp_base, acc1);
+        proj_pass<PREC, TA, NTP, NPASS, 0, A_PLANE, MT, 2>(a, t, smA, bf, stamp_base, acc0);
+        proj_pass<PREC, TA, NTP, NPASS, 1, A_PLANE, MT, 2>(a, t, smA, bf, stamp_base, acc1);
+    } else {
+        proj_pass<PREC, TA, NTP, NPASS, 0, A_PLANE, MT, 0>(a, t, smA, bf, stamp_base, acc0);
+        proj_pass<PREC, TA, NTP, NPASS, 1, A_PLANE, MT, 0>(a, t, smA, bf, stamp_base, acc0);
+    }
+#else
     proj_pass<PREC, TA, NTP, NPASS, 0, A_PLANE, MT>(a, t, smA, bf, stamp_base);
     proj_pass<PREC, TA, NTP, NPASS, 1, A_PLANE, MT>(a, t, smA, bf, stamp_base);
+#endif
 }
 
 }  // namespace lg

@@ -24,7 +24,7 @@ print('$1 ${2:-bf16x3}', round(d['value']), round(d['ms_per_step'], 3), 'tail', 
 for round in 1 2; do
   ab lightglue_amd/liblightglue_amd.so
   ab lightglue_amd/liblightglue_amd.so f16x3
-  for v in o1 o2 gs o1gs o2gs pe; do [ -f lightglue_amd/liblightglue_amd_sched_$v.so ] && ab lightglue_amd/liblightglue_amd_sched_$v.so; done
+  for v in o1 o2 gs o1gs o2gs pe pp o1gspp; do [ -f lightglue_amd/liblightglue_amd_sched_$v.so ] && ab lightglue_amd/liblightglue_amd_sched_$v.so; done
   [ -f lightglue_amd/liblightglue_amd_fold.so ] && ab lightglue_amd/liblightglue_amd_fold.so
   [ -f lightglue_amd/liblightglue_amd_ablw.so ] && ab lightglue_amd/liblightglue_amd_ablw.so   # TIMING ABLATION (wrong results, parity column meaningless): projection without weight loads
 done 2>&1 | tee $O/ab.log

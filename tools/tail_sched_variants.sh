@@ -1,5 +1,5 @@
 #!/bin/bash
-# Scheduling experiments on the fused tail (lg_tail.hip: LG_TAIL_STEP_ORDER / LG_TAIL_GELU_SCALAR; lg_proj_body.h: LG_PROJ_EPI_PREFETCH, fused projection only).  Every variant computes the
+# Scheduling experiments on the fused tail (lg_tail.hip: LG_TAIL_STEP_ORDER / LG_TAIL_GELU_SCALAR; lg_proj_body.h: LG_PROJ_EPI_PREFETCH / LG_PROJ_PINGPONG, fused projection only; the two are alternatives, not to be combined).  Every variant computes the
 # same values in the same per-element order as the product build, so outputs must be bit-identical to it.
 #   tools/tail_sched_variants.sh build          (here, in the build container: the .so files travel with gpurun)
 #   tools/tail_sched_variants.sh ab             (on the GPU box, ONE gpurun call: whole-step A/B, two rounds — DESIGN.md §5: only
@@ -7,7 +7,7 @@
 #   tools/tail_sched_variants.sh parity         (on the GPU box: the golden parity tests against each variant)
 set -e
 cd "$(dirname "$0")/.."
-VARIANTS="o1:-DLG_TAIL_STEP_ORDER=1 o2:-DLG_TAIL_STEP_ORDER=2 gs:-DLG_TAIL_GELU_SCALAR=1 o1gs:-DLG_TAIL_STEP_ORDER=1,-DLG_TAIL_GELU_SCALAR=1 o2gs:-DLG_TAIL_STEP_ORDER=2,-DLG_TAIL_GELU_SCALAR=1 pe:-DLG_PROJ_EPI_PREFETCH=1"
+VARIANTS="o1:-DLG_TAIL_STEP_ORDER=1 o2:-DLG_TAIL_STEP_ORDER=2 gs:-DLG_TAIL_GELU_SCALAR=1 o1gs:-DLG_TAIL_STEP_ORDER=1,-DLG_TAIL_GELU_SCALAR=1 o2gs:-DLG_TAIL_STEP_ORDER=2,-DLG_TAIL_GELU_SCALAR=1 pe:-DLG_PROJ_EPI_PREFETCH=1 pp:-DLG_PROJ_PINGPONG=1 o1gspp:-DLG_TAIL_STEP_ORDER=1,-DLG_TAIL_GELU_SCALAR=1,-DLG_PROJ_PINGPONG=1"
 case "$1" in
   build)
     # only lg_tail.o differs: compile that file per variant and link it with the product build's other objects

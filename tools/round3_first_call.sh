@@ -1,7 +1,7 @@
 #!/bin/bash
 # First GPU call of the next round: everything below was BUILT at the end of round 2 without GPU minutes left.
-# In the build container first:   tools/tail_sched_variants.sh build ; tools/build_variant.sh ctx6 -DLG_EXPERIMENTS -DLG_TAIL_CTX_FP6=1 ; tools/build_variant.sh fold -DLG_ATTN_FOLD=1 ; tools/build_variant.sh ablw -DLG_PROJ_ABLATE_W=1
-# then:   gpurun --timeout 1500 -- 'bash tools/round3_first_call.sh'        (≈15-20 min of box time; results in gpurun_out/round3/)
+# In the build container first:   tools/tail_sched_variants.sh build (≈10 min: the sched_group_barrier builds compile slowly) ; tools/build_variant.sh ctx6 -DLG_EXPERIMENTS -DLG_TAIL_CTX_FP6=1 ; tools/build_variant.sh fold -DLG_ATTN_FOLD=1 ; tools/build_variant.sh ablw -DLG_PROJ_ABLATE_W=1
+# then:   gpurun --timeout 1800 -- 'bash tools/round3_first_call.sh'        (≈20-25 min of box time; results in gpurun_out/round3/)
 mkdir -p gpurun_out/round3; O=gpurun_out/round3
 export TMPDIR=/tmp
 # 1. precision "f16x3" (split scheme on f16 planes): the gated parity tests + per-golden margins next to the default's

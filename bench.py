@@ -6,7 +6,7 @@ and early-stop OFF, batch 32 pairs per GPU, inputs resident in HBM, synthetic da
 One "step" = one LightGlue.forward over one batch of 32 pairs (the whole reference forward: layers,
 log-assignment, match filtering and the ragged match lists).
 
-    python bench.py [--gpus N --steps K --warmup W] [--precision bf16x3|f16x3|bf16|fp16|fp32]
+    python bench.py [--gpus N --steps K --warmup W] [--precision f16x3|bf16|fp16|fp32] [--attention fp16]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -61,17 +61,31 @@ def flops_per_launch(pairs: int, n: int, m: int):
     }
 
 
-# HBM bytes per launch of the dominant kernel measured with rocprofv3 PMC passes (FETCH_SIZE x 2 per the gfx950
-# correction in MI355X_MICROARCH.md + WRITE_SIZE; KB in the tables), profiles/r02d_pmc_{fetch,write}.md; valid for the default
-# workload only.  "+next": the tail kernel that also runs the next block's projection: average over the 8 launches with a
-# SelfBlock projection (NEXT = 1), the 9 with a CrossBlock projection (NEXT = 2) and the last, plain one (NEXT = 0).
-PMC_TRAFFIC_BYTES = {("bf16x3", 32, 1024, "fused_tail"): (2 * 1.2e5 + 9.281e4) * 1024,
-                     ("bf16x3", 32, 1024, "fused_tail+next"): (8 * (2 * 1.433e5 + 1.932e5) + 9 * (2 * 1.275e5 + 1.602e5)
-                                                               + (2 * 1.2e5 + 9.281e4)) / 18 * 1024}
+# HBM bytes per launch measured with rocprofv3 PMC passes of THIS command (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x 2 per
+# the gfx950 correction in MI355X_MICROARCH.md), written by tools/pmc_traffic.py to profiles/pmc_traffic.json together with a digest
+# of the kernel sources they were measured on.  bench.py reports them only while that digest matches the tree (a changed kernel ->
+# "traffic": null with the reason), so the constant cannot go stale silently.
+PMC_TRAFFIC_FILE = ROOT / "profiles" / "pmc_traffic.json"
 
 
-# the two log-assignment sweeps (profiles/r02d_pmc_{fetch,write}.md): 2 x FETCH_SIZE + WRITE_SIZE of lse_sweep + argmax_sweep
-PMC_TRAFFIC_ASSIGN = {("bf16x3", 32, 1024): (2 * 6.556e4 + 8320 + 2 * 6.671e4 + 8448) * 1024}
+def kernel_source_digest() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "lightglue_amd" / "csrc").glob("lg_*")):
+        h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(key: str):
+    """(bytes per launch or None, source note) for `key` = "<precision>/<attention>/B<pairs>/N<kpts>/<kernel class>"."""
+    try:
+        rec = json.loads(PMC_TRAFFIC_FILE.read_text())
+    except (OSError, ValueError):
+        return None, "profiles/pmc_traffic.json missing: run tools/pmc_traffic.py on the GPU box"
+    if rec.get("kernel_source_digest") != kernel_source_digest():
+        return None, f"stale: profiles/pmc_traffic.json was measured on kernel sources {rec.get('kernel_source_digest')}, the tree is {kernel_source_digest()} (re-run tools/pmc_traffic.py)"
+    v = rec.get("bytes_per_launch", {}).get(key)
+    return v, rec.get("source", "profiles/pmc_traffic.json") if v is not None else f"no entry {key} in profiles/pmc_traffic.json"
 
 
 def hbm_bytes_assign(pairs: int, n: int, m: int) -> float:
@@ -124,6 +138,58 @@ def _time_reference(sd, n, threads, reps, warm=2):
         torch.set_num_threads(old)
 
 
+class _ParallelElementwise:
+    """Timed CPU leg only: numpy runs the port's elementwise / row-wise passes (softmax exp over 4 N^2 values per attention call,
+    erf-GELU, LayerNorm, log-softmax) on ONE core while torch parallelises them in the real reference, which made the port 4-5x
+    slower than the reference at 8 threads although its GEMMs are as fast.  Inside this context the oracle's
+    row-wise helpers run on row chunks in a thread pool (numpy ufuncs release the GIL).  Every row is still computed by the
+    same numpy code, so results are bit-identical to the plain oracle (tests/test_host_api.py checks that); the checker used
+    by the tests is the unpatched module."""
+    NAMES = ("_softmax", "_log_softmax", "_gelu", "_layernorm")
+
+    def __init__(self, threads):
+        self.threads = max(1, int(threads))
+
+    def __enter__(self):
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import lightglue_oracle as O
+        self.O, self.saved = O, {k: getattr(O, k) for k in self.NAMES}
+        if self.threads > 1:
+            self.pool = ThreadPoolExecutor(self.threads)
+            for k, fn in self.saved.items():
+                setattr(O, k, self._wrap(fn))
+        return self
+
+    def __exit__(self, *exc):
+        for k, fn in self.saved.items():
+            setattr(self.O, k, fn)
+        if self.threads > 1:
+            self.pool.shutdown()
+
+    def _wrap(self, fn):
+        pool, parts = self.pool, self.threads
+
+        def run(x, *a, **k):
+            rows = x.shape[-2] if x.ndim >= 2 else 0
+            if rows < 4 * parts or k.get("axis", a[0] if a and isinstance(a[0], int) else -1) not in (-1, x.ndim - 1):
+                return fn(x, *a, **k)
+            cut = np.linspace(0, rows, parts + 1).astype(int)
+            return np.concatenate(list(pool.map(lambda i: fn(x[..., cut[i]:cut[i + 1], :], *a, **k), range(parts))), axis=-2)
+        return run
+
+
+def timed_port_forward(sd, conf, data, threads):
+    from oracle import lightglue_oracle as O
+    with _ParallelElementwise(threads):
+        return O.forward(sd, conf, data)
+
+
+def _port_over_reference(n, threads):
+    """Measured time ratio port / reference for the nearest measured (N, threads) cell of profiles/r03_cpu_reference.md."""
+    row = PORT_OVER_REFERENCE_TIME["1 thread" if threads <= 2 else "8 threads"]
+    return row["N=512" if n <= 768 else "N=1024"]
+
+
 def cpu_baseline(sd, n, m, gpu_out=None, budget_s=12.0, max_pairs=8):
     """CPU leg (rank 0, N = 1 only; ~20-30 s in total).  The numpy port of the reference's CPU fp32 path (oracle/) is timed on
     pairs of the SAME seeded batch the GPU matched (pair seeds 1, 2, ...), so the same calls also CHECK the GPU result
@@ -141,7 +207,7 @@ def cpu_baseline(sd, n, m, gpu_out=None, budget_s=12.0, max_pairs=8):
     probe = synthetic.make_batch(999, 1, n, m)
     for th in sorted({1, min(8, ncpu), min(16, ncpu), min(32, ncpu)}):
         with threadpool_limits(limits=th):
-            t0 = time.perf_counter(); O.forward(sd, conf, probe); t = time.perf_counter() - t0
+            t0 = time.perf_counter(); timed_port_forward(sd, conf, probe, th); t = time.perf_counter() - t0
         if t < best_t:
             best, best_t = th, t
     done, t0 = 0, time.perf_counter()
@@ -149,7 +215,7 @@ def cpu_baseline(sd, n, m, gpu_out=None, budget_s=12.0, max_pairs=8):
     with threadpool_limits(limits=best):
         while done < max_pairs:
             data = synthetic.make_batch(1 + done, 1, n, m)      # == pair `done` of rank 0's GPU batch
-            refs.append(O.forward(sd, conf, data))
+            refs.append(timed_port_forward(sd, conf, data, best))
             done += 1
             if time.perf_counter() - t0 > budget_s:
                 break
@@ -159,16 +225,19 @@ def cpu_baseline(sd, n, m, gpu_out=None, budget_s=12.0, max_pairs=8):
     d512 = synthetic.make_batch(1, 1, 512, 512)
     for th in sorted({1, best}):
         with threadpool_limits(limits=th):
-            O.forward(sd, conf, d512)
-            t1 = time.perf_counter(); O.forward(sd, conf, d512); O.forward(sd, conf, d512)
+            timed_port_forward(sd, conf, d512, th)
+            t1 = time.perf_counter(); timed_port_forward(sd, conf, d512, th); timed_port_forward(sd, conf, d512, th)
             cfg1[f"{th} thread(s)"] = round(2.0 / (time.perf_counter() - t1), 3)
     res = {"value": done / dt, "unit": "image-pairs/s", "cores": best, "kind": "port",
-           "sample": f"{done} pair(s) N=M={n} of the benchmark's own batch, 9 layers, fp32 numpy/OpenBLAS port of the reference CPU path, {dt:.1f}s, "
-                     f"{best} BLAS thread(s) (fastest of 1/8/16/32 on {ncpu} logical cores)",
+           "sample": f"{done} pair(s) N=M={n} of the benchmark's own batch, 9 layers, fp32 numpy/OpenBLAS port of the reference CPU path "
+                     f"(row-wise passes chunked over the same {best} threads), {dt:.1f}s, "
+                     f"{best} thread(s) (fastest of 1/8/16/32 on {ncpu} logical cores)",
            "cpu_model": _cpu_model(), "logical_cores": ncpu,
            "cfg1_n512_b1_pairs_per_s": cfg1,
            "port_over_reference_time_ratio": PORT_OVER_REFERENCE_TIME,
-           "port_over_reference_note": "measured in the build container (8 vCPU Xeon 2.1 GHz); the reference itself is ~1.3x (1 thread) to ~4x (8 threads) faster than this port"}
+           "port_over_reference_source": "profiles/r03_cpu_reference.md (tools/cpu_reference_table.py: the unmodified reference and this port timed side by side in the build container)",
+           # what the REAL reference would do on these cores, by the measured ratio (the GPU box has no /root/reference)
+           "reference_estimate_pairs_per_s": round(done / dt * _port_over_reference(n, best), 3)}
     if REFERENCE_FILE.exists():   # build container only: time the real thing beside the port
         try:
             ref_t = {f"N={k} {th} thread(s)": round(1.0 / _time_reference(sd, k, th, reps=3), 3) for k in (512, n) for th in sorted({1, min(8, ncpu)})}
@@ -223,7 +292,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f16x3", "bf16", "fp16", "fp32"])   # f16x3: opt-in, see DESIGN.md §1
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16", "fp16", "fp32"])
+    ap.add_argument("--attention", default=None, choices=["fp16"], help="with --precision f16x3: the single-plane f16 attention (fast opt-in, outside the bar for sharp attention)")
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per step")
     ap.add_argument("--kpts", type=int, default=N_KPTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -255,7 +325,7 @@ def main():
     n = m = args.kpts
     B = args.pairs
     sd = synthetic.make_state_dict(0, recipe="A")
-    model = LightGlue(features=None, depth_confidence=-1, width_confidence=-1, precision=args.precision).eval()
+    model = LightGlue(features=None, depth_confidence=-1, width_confidence=-1, precision=args.precision, attention_precision=args.attention).eval()
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     data_np = synthetic.make_batch(1 + rank * B, B, n, m)
     data = {k: {kk: torch.from_numpy(vv).to(dev) for kk, vv in v.items()} for k, v in data_np.items()}
@@ -340,11 +410,47 @@ def main():
     prof = model.profile_read(dev)
     model.profile(False, dev)
 
+    rccl = None
+    sync_value = None
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # what the collective looked like from inside the job (SCALE_r*.json then shows that RCCL saw N ranks): the result gather of
+        # one step timed ALONE with events on this rank's stream (in the timed loop it runs on a side stream under the next forward)
+        width = 2 * n + 2 * m + 1
+        send = torch.zeros((B, width), dtype=torch.int32, device=dev)
+        recv = torch.empty((B * world, width), dtype=torch.int32, device=dev)
+        via_host = dist.get_backend() == "gloo"
+        def one_gather():
+            if via_host:
+                r = torch.empty((B * world, width), dtype=torch.int32); dist.all_gather_into_tensor(r, send.cpu())
+            else:
+                dist.all_gather_into_tensor(recv, send)
+        for _ in range(3):
+            one_gather()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev); e0.record()
+        for _ in range(20):
+            one_gather()
+        e1.record(); torch.cuda.synchronize(dev)
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(dev)})
+        rccl = {"world": dist.get_world_size(), "backend": dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else " (debug backend, host copies)"),
+                "ranks_seen": seen, "gather": "all_gather_into_tensor of one packed int32 buffer [pairs, 2n + 2m + 1] per step (matches0 | scores0 bits | matches1 | scores1 bits | stop)",
+                "gather_bytes_sent_per_rank": int(send.numel() * 4), "gather_bytes_received_per_rank": int(recv.numel() * 4),
+                "gather_ms_alone": e0.elapsed_time(e1) / 20, "gather_overlap": "issued on a side stream behind an event; step i's gather runs under step i+1's forward"}
+    elif not args.no_pipeline:
+        # the reference's forward() is synchronous; the headline loop defers each step's host sync by one step.  The same K
+        # steps once more with a synchronous forward per step, reported beside it
+        torch.cuda.synchronize(dev)
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            out_sync = model(data)
+        torch.cuda.synchronize(dev)
+        sync_value = B * args.steps / (time.perf_counter() - ts)
+        del out_sync
 
     if rank == 0:
         total_pairs = B * world * args.steps
@@ -361,6 +467,9 @@ def main():
         dom_ms = timed[dom][0] / timed[dom][1]
         achieved = fl[dom] / (dom_ms * 1e-3) / 1e12
         peak = 157.3 if args.precision == "fp32" else 2500.0  # dense MFMA peak, MI355X_MICROARCH.md
+        tkey = f"{args.precision}/{args.attention or args.precision}/B{B}/N{n}/"
+        traffic_dom = pmc_traffic(tkey + dom + ("+next" if fused_next and dom == "fused_tail" else ""))
+        traffic_assign = pmc_traffic(tkey + "assign_sweeps")
         if warm_prof:   # per-class table from the warm-up steps; the dominant class from the timed region
             kernel_ms = {k: round(v[0], 4) for k, v in warm_prof.items()}
             kernel_ms[dom] = round(timed[dom][0] / args.steps, 4)
@@ -378,21 +487,24 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"bf16x3": "bf16", "f16x3": "f16", "bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.precision],
+            # the arithmetic type of the matrix-core operands: split f16 (hi + lo planes, 22 bits, three v_mfma_f32_16x16x32_f16 per
+            # product) is WIDER than the bf16 BASELINE cfg #2 names, at the same storage width and MFMA rate per instruction
+            "dtype": {"f16x3": "f16", "bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"SuperPoint-dim 256-d descriptors, N=M={n}, 9 layers, pruning/early-stop OFF, batch={B} pairs per GPU, "
                                    f"seeded random weights (recipe A), precision={args.precision}"
-                                   + (" (split-bf16 MFMA x3 for linear layers + f16 attention, fp32 accumulate/residual)" if args.precision == "bf16x3" else ""),
+                                   + (" (split-f16 operands, 3 MFMAs per product, for every contraction incl. q k^T and P V; fp32 accumulate / residual / softmax)" if args.precision == "f16x3" and not args.attention else "")
+                                   + (", attention_precision=fp16 (single-plane f16 attention: the fast opt-in, outside the 1e-3 bar for sharp attention)" if args.attention else ""),
                        "pairs_per_gpu": B, "keypoints": n, "parallelism": f"pair-sharded dp{world}",
                        "host_pipelining": ("result gather of step i overlaps the forward of step i+1" if world > 1 else
                                            "synchronous forward per step" if args.no_pipeline else
                                            "output assembly (the forward's one host sync) of step i overlaps the forward of step i+1; all K outputs are built inside the timed region")},
             "roofline": {"bound": "mfma", "kernel": dom + (" (+ next block's q/k/v projection)" if fused_next and dom == "fused_tail" else ""), "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": PMC_TRAFFIC_BYTES.get((args.precision, B, n, dom + ("+next" if fused_next and dom == "fused_tail" else ""))), "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE passes of this same command, profiles/r02d_pmc_{fetch,write}.md — a constant from those passes, not re-measured inside this run",
+                         "traffic": traffic_dom[0], "traffic_source": traffic_dom[1],
                          "avg_launch_ms": dom_ms, "algorithmic_flops_per_launch": fl[dom],
                          "sustained_peak": sustained_tflops, "frac_of_sustained": (achieved / sustained_tflops if sustained_tflops else None),
-                         "note": "algorithmic FLOPs (2/MAC) of one launch / HIP-event launch duration; split-bf16 issues 3 MFMAs per algorithmic MAC "
-                                 "(2 in the fused q/k/v projection).  peak = nominal dense bf16 (2.4 GHz); sustained_peak = what a dense bf16 MFMA spin "
+                         "note": "algorithmic FLOPs (2/MAC) of one launch / HIP-event launch duration; split f16 issues 3 MFMAs per algorithmic MAC.  "
+                                 "peak = nominal dense bf16 / f16 (2.4 GHz); sustained_peak = what a dense bf16 MFMA spin "
                                  "reaches on THIS box right before the timed region (power-managed clock, see effective_mfma_clock_mhz)"},
             # the HBM-bound stage of the path: dual log-softmax + argmax sweeps over the similarity matrix
             "roofline_hbm": ({"bound": "hbm", "kernel": "assign (lse_sweep + argmax_sweep + merges + finalize)",
@@ -400,8 +512,7 @@ def main():
                               "peak": 8000.0, "unit": "GB/s",
                               "frac": hbm_bytes_assign(B, n, m) / (timed["assign"][0] / timed["assign"][1] * 1e-3) / 1e9 / 8000.0,
                               "algorithmic_bytes_per_launch": hbm_bytes_assign(B, n, m),
-                              "traffic": PMC_TRAFFIC_ASSIGN.get((args.precision, B, n)),
-                              "traffic_source": "profiles/r02d_pmc_{fetch,write}.md (constant from the PMC passes, not re-measured in this run)"} if "assign" in timed else None),
+                              "traffic": traffic_assign[0], "traffic_source": traffic_assign[1]} if "assign" in timed else None),
             "kernel_ms_per_step": kernel_ms,
             "kernel_ms_per_step_source": ("HIP events around every launch during the warm-up steps; the roofline kernel's entry and "
                                           "avg_launch_ms come from events inside the timed region") if warm_prof else "HIP events inside the timed region",
@@ -411,10 +522,12 @@ def main():
             # boxes differ by up to ~20 % for one binary, and most of it is this clock
             "effective_mfma_clock_mhz": sustained_mhz, "sustained_dense_bf16_tflops": sustained_tflops,
             "matches_per_pair": float(np.mean([(o > -1).sum().item() for o in out["matches0"]])) if "matches0" in out else None,
+            "value_synchronous_forward": sync_value,   # pairs/s with model(data) per step (host sync inside every forward), N = 1 only
+            "rccl": rccl,
         }
         # match-index parity of the batch that was just timed (rank 0's pairs): against the reference's own fixture for the
         # first 4 pairs and against the oracle on the pairs the CPU leg runs anyway
-        default_weights = args.precision in ("bf16x3", "f16x3", "fp32")
+        default_weights = args.precision in ("f16x3", "fp32")
         res["parity"] = golden_parity(out, n, B) if default_weights else None
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"], res["parity_oracle"] = cpu_baseline(sd, n, m, gpu_out=out)

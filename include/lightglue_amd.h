@@ -19,14 +19,17 @@ extern "C" {
 
 /* Operand precision of the matrix-core contractions (accumulation is always fp32). */
 enum {
-    LG_PREC_F32 = 0,    /* v_mfma_f32_16x16x4_f32: exact fp32 products (parity anchor)            */
-    LG_PREC_BF16 = 1,   /* v_mfma_f32_16x16x32_bf16                                                */
-    LG_PREC_F16 = 2,    /* v_mfma_f32_16x16x32_f16                                                 */
-    LG_PREC_BF16X3 = 3, /* split bf16 (hi+lo, 3 MFMAs) for linear layers / similarity; attention
-                           runs in f16 like the reference's GPU path (lightglue.py:119)          */
-    LG_PREC_F16X3 = 4   /* the same split scheme on f16 planes (same cost, ~100x smaller product
-                           error in emulation; needs |x| < 65504).  Opt-in: built, NOT yet
-                           validated on the GPU                           */
+    LG_PREC_F32 = 0,    /* v_mfma_f32_16x16x4_f32: exact fp32 products (parity anchor)                              */
+    LG_PREC_BF16 = 1,   /* v_mfma_f32_16x16x32_bf16, one MFMA per product: fast, does NOT hold the 1e-3 score bar    */
+    LG_PREC_F16 = 2,    /* v_mfma_f32_16x16x32_f16, one MFMA per product: fast, does NOT hold the 1e-3 score bar     */
+    /* 3 was split-bf16 (rounds 1-2): same cost as LG_PREC_F16X3 at 3x its score error — removed in round 3            */
+    LG_PREC_F16X3 = 4   /* DEFAULT.  split f16: x = hi + lo (both f16, 22 bits), 3 MFMAs per product, for every linear
+                           layer, the similarity matrix AND — with attn_precision = LG_PREC_F16X3, the default — for q k^T
+                           and P V of the attention (q / k / v and the probabilities kept as hi + lo planes).  Holds the
+                           bar also when attention logits are sharp (recipe-D fixtures).  Needs |x| < 65504, like the
+                           reference's own fp16 mode.  attn_precision = LG_PREC_F16 is the fast opt-in: q / k / v as ONE f16
+                           plane (what the reference's GPU path feeds its fp16 SDPA, lightglue.py:119), 2 MFMAs per
+                           product in the q/k/v projections — within the bar only while attention is diffuse            */
 };
 
 #define LG_OK 0
@@ -46,7 +49,7 @@ typedef struct lg_config {
     double filter_threshold;    /* lightglue.py:592                                               */
     int32_t pruning_min_kpts;   /* resolved LightGlue.pruning_min_kpts() (lightglue.py:658-662)   */
     int32_t precision;          /* LG_PREC_*                                                      */
-    int32_t attn_precision;     /* LG_PREC_F32/BF16/F16 or -1 = derive from `precision`           */
+    int32_t attn_precision;     /* -1 = `precision`; or LG_PREC_F16 together with LG_PREC_F16X3   */
 } lg_config;
 
 typedef struct lg_engine lg_engine;
@@ -111,16 +114,13 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream);
 
 /* Engine options (defaults are the product configuration; the others exist for tests, A/B measurements and profiling):
  *   "fused_tail"   1  out_proj + ffn + LayerNorm + GELU + residual as one kernel (lg_tail.hip); 0 = per-op GEMM kernels
- *   "fused_proj"   1  full-width q/k/v projection kernel (lg_proj.hip); 0 = generic GEMM with the QKV epilogue
  *   "fused_next"   1  the tail kernel also runs the NEXT block's q/k/v projection on the x tile it has just produced
- *                     (bit-identical to the separate kernel; needs fused_tail, fused_proj and 16-bit operand precisions)
- *   "tail_variant" 0  product library: only 0 (lg_tail.hip) is accepted.  Experiment builds (make EXPERIMENTS=1 / -DLG_EXPERIMENTS) add
- *                     the lg_tail4.hip decompositions 1 = 4 waves x 64 rows, 2 = 8 waves x 128 rows, 3 = 4 waves x 32 rows (all
- *                     correct, none faster) and the LG_TAIL_VARIANT / LG_ATTN_ROWS environment switches; the product reads no environment
- *   "attn_rows"    -  query rows per attention wave: 16 | 32 | 64 (bit-identical outputs).  Unset: 32, and 16 when a launch has
- *                     fewer 128-row workgroups than the chip has CUs (single pairs); setting it pins the shape
- *   "attn_dma"     1  16-bit, 32 rows per wave: K / V^T tiles reach LDS by DMA (two buffers, one barrier per tile, 4 waves per
- *                     SIMD); 0 = the register-staged kernel (bit-identical)
+ *                     (bit-identical to the separate kernel; needs fused_tail and 16-bit operand precisions)
+ *   "attn_rows"    -  query rows per attention wave: 16 | 32 | 64 (bit-identical outputs; the split attention has 16 | 32).  Unset:
+ *                     32, and 16 when a launch has fewer 128-row workgroups than the chip has CUs (single pairs); setting it pins
+ *                     the shape
+ *   "attn_dma"     1  single-plane 16-bit attention, 32 rows per wave: K / V^T tiles reach LDS by DMA (two buffers, one barrier per
+ *                     tile, 4 waves per SIMD); 0 = the register-staged kernel (bit-identical).  The split attention is always DMA
  *   "tail_row_tiles" 0  16-row tiles per fused-tail workgroup: 4 (64 rows) | 2 | 1, 0 = by grid fill (small grids take the
  *                     smaller shapes; bit-identical outputs; the exact fp32 mode always uses 4)
  *   "profile_only" -1 restrict the HIP-event timing of lg_engine_profile_enable to one kernel class (index of

@@ -14,7 +14,7 @@ from pathlib import Path
 # a build of this package's csrc/ — there is no other implementation to fall back to.
 _LIB_PATH = Path(os.environ.get("LIGHTGLUE_AMD_LIB") or Path(__file__).resolve().parent / "liblightglue_amd.so")
 
-LG_PREC = {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3, "f16x3": 4}
+LG_PREC = {"fp32": 0, "bf16": 1, "fp16": 2, "f16x3": 4}   # include/lightglue_amd.h LG_PREC_* (3 was split-bf16, removed in round 3)
 LG_OK, LG_ERR_INVALID, LG_ERR_HIP, LG_ERR_STATE = 0, 1, 2, 3
 LG_FLAG_NO_PRUNING = 1
 

@@ -16,17 +16,10 @@
 //           S^T acc[kt][qt][r] <-> key 32*(kt>>1) + 8*g + 4*(kt&1) + r,   PV chunk tp: B element j <-> key 32*tp + 8*g + j
 // V is produced TRANSPOSED by the projection ([head][d][row]) so the matching A operand is ONE contiguous 16-byte
 // LDS read per fragment in both cases (the natural order needed two 8-byte reads + register shuffles).
-// The S matrix never touches HBM.  Softmax runs in fp32 with exp2 and a folded log2(e)/sqrt(64).
+// The S matrix never touches HBM.  q and k arrive pre-multiplied by sqrt(log2(e) / sqrt(64)) (lg_proj_body.h QK_PRESCALE, the
+// reference's CPU path splits its scale the same way, lightglue.py:215), so S is already the base-2 logit: softmax runs in fp32
+// with bare exp2, and in the LDS-DMA kernels the score accumulators START at -m_run so that exp2 applies to the MFMA result.
 #include "lg_kernels.h"
-
-// Experiment (tools/build_variant.sh fold -DLG_ATTN_FOLD=1; the product build leaves it at 0 and its machine code is unchanged):
-// q and k leave the projection pre-multiplied by sqrt(log2(e) / 8) (lg_proj_body.h, as the reference's own CPU path splits its scale
-// over both operands, lightglue.py:215), and the LDS-DMA kernel starts every score accumulator at -m_run instead of 0, so that
-// exp2 applies to the MFMA result directly: 32 v_fma_f32 fewer per 64-key tile in a loop that is bound by VALU issue.
-// Not bit-identical to the default (q, k are rounded to f16 after the scaling instead of before) — same error class.
-#ifndef LG_ATTN_FOLD
-#define LG_ATTN_FOLD 0
-#endif
 
 namespace lg {
 
@@ -205,11 +198,7 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
             const float t4 = vmax3(s[3][qt][0], s[3][qt][1], s[3][qt][2]);
             float mx = vmax2(vmax3(t0, t1, t2), vmax3(t3, t4, s[3][qt][3]));
             mx = xor32_max(xor16_max(mx));   // the 4 lane groups of a query column, no LDS round trip
-#if LG_ATTN_FOLD
-            m_new[qt] = vmax2(m_run[qt], mx);                    // (q, k carry the scale)
-#else
-            m_new[qt] = vmax2(m_run[qt], mx * a.scale_log2e);   // finite: every tile holds >= 1 live key (scale > 0)
-#endif
+            m_new[qt] = vmax2(m_run[qt], mx);   // finite: every tile holds >= 1 live key (q, k carry the score scale)
             grew = grew || (m_new[qt] > m_run[qt] + 8.f);
         }
         // Deferred rescale (guide T13): keep the stale running maximum while no row's maximum grew by more than 2^8
@@ -231,20 +220,16 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
     auto sexp = [&](f32x4 (&s)[4][QT]) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            // exp2(s*c - m) with SCALAR v_fma_f32 / v_add_f32 and the bare v_exp_f32 (arguments <= 8, flush-to-zero tail is
-            // fine).  Packed f32 ops (v_pk_fma_f32 / v_pk_add_f32) are cheaper on their own but barely co-issue with another
-            // wave's MFMAs on the SIMD (tools/ubench/mfma_valu_overlap.hip: 24 % overlap vs 79 % for v_fma_f32), and this
-            // kernel lives on that overlap.  Two partial sums keep the add chain short.
-#if LG_ATTN_FOLD
-            const float sc = 1.0f, nm = -m_run[qt];
-#else
-            const float sc = a.scale_log2e, nm = -m_run[qt];
-#endif
+            // exp2(s - m) with SCALAR v_sub_f32 / v_add_f32 and the bare v_exp_f32 (arguments <= 8, flush-to-zero tail is
+            // fine).  Packed f32 ops (v_pk_add_f32) are cheaper on their own but barely co-issue with another wave's MFMAs on
+            // the SIMD (tools/ubench/mfma_valu_overlap.hip: 24 % overlap vs 79 % for scalar ops), and this kernel lives on that
+            // overlap.  Two partial sums keep the add chain short.
+            const float nm = m_run[qt];
             float rs0 = 0.f, rs1 = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][0], sc, nm)), p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][1], sc, nm));
-                const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][2], sc, nm)), p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][3], sc, nm));
+                const float p0 = __builtin_amdgcn_exp2f(s[kt][qt][0] - nm), p1 = __builtin_amdgcn_exp2f(s[kt][qt][1] - nm);
+                const float p2 = __builtin_amdgcn_exp2f(s[kt][qt][2] - nm), p3 = __builtin_amdgcn_exp2f(s[kt][qt][3] - nm);
                 s[kt][qt][0] = p0; s[kt][qt][1] = p1; s[kt][qt][2] = p2; s[kt][qt][3] = p3;
                 rs0 += p0 + p2; rs1 += p1 + p3;
             }
@@ -412,11 +397,7 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_dma_kernel(AttnArgs a) {
     float m_run[QT], l_run[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-#if LG_ATTN_FOLD
         m_run[qt] = 0.f; l_run[qt] = 0.f;          // finite: the accumulators start at -m_run; the first tile always re-bases (below)
-#else
-        m_run[qt] = -INFINITY; l_run[qt] = 0.f;
-#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -459,11 +440,7 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_dma_kernel(AttnArgs a) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-#if LG_ATTN_FOLD
             for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{-m_run[qt], -m_run[qt], -m_run[qt], -m_run[qt]};   // scores arrive as s - m_run (the first MFMA of a chain reads this tuple as its C operand)
-#else
-            for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
@@ -483,7 +460,6 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_dma_kernel(AttnArgs a) {
                     for (int r = 0; r < 4; ++r)
                         if (kv0 + 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r >= kvlen) s[kt][qt][r] = -INFINITY;
         }
-#if LG_ATTN_FOLD
         // s holds d = score - m_run.  Row maximum of d; re-base when it exceeds 8 (deferred rescale: p <= 2^8 otherwise) and
         // always on the first tile (m_run = 0 there is arbitrary; the re-base may go DOWN, so alpha is not used for it: l = o = 0)
         float dmax[QT];
@@ -523,44 +499,6 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_dma_kernel(AttnArgs a) {
             }
             l_run[qt] += rs0 + rs1;
         }
-#else
-        float m_new[QT];
-        bool grew = false;
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const float t0 = vmax3(s[0][qt][0], s[0][qt][1], s[0][qt][2]), t1 = vmax3(s[0][qt][3], s[1][qt][0], s[1][qt][1]);
-            const float t2 = vmax3(s[1][qt][2], s[1][qt][3], s[2][qt][0]), t3 = vmax3(s[2][qt][1], s[2][qt][2], s[2][qt][3]);
-            const float t4 = vmax3(s[3][qt][0], s[3][qt][1], s[3][qt][2]);
-            float mx = vmax2(vmax3(t0, t1, t2), vmax3(t3, t4, s[3][qt][3]));
-            mx = xor32_max(xor16_max(mx));
-            m_new[qt] = vmax2(m_run[qt], mx * a.scale_log2e);
-            grew = grew || (m_new[qt] > m_run[qt] + 8.f);
-        }
-        if (__any(grew)) {   // deferred rescale, see attn_kernel
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new[qt]);
-                l_run[qt] *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) o[dt][qt] *= alpha;
-                m_run[qt] = m_new[qt];
-            }
-        }
-        ATT_TICK(3);
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const float sc = a.scale_log2e, nm = -m_run[qt];
-            float rs0 = 0.f, rs1 = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][0], sc, nm)), p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][1], sc, nm));
-                const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][2], sc, nm)), p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][3], sc, nm));
-                s[kt][qt][0] = p0; s[kt][qt][1] = p1; s[kt][qt][2] = p2; s[kt][qt][3] = p3;
-                rs0 += p0 + p2; rs1 += p1 + p3;
-            }
-            l_run[qt] += rs0 + rs1;
-        }
-#endif
         ATT_TICK(4);
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp) {
@@ -603,6 +541,257 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_dma_kernel(AttnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// SPLIT-f16 attention (attention precision PREC_F16X3, the default): q, k, v arrive as hi + lo f16 planes (lg_proj_body.h,
+// 22 operand bits) and the probabilities are split the same way, so both contractions run as three MFMAs per product
+//      S^T = Kh Ql^T + Kl Qh^T + Kh Qh^T          O^T = Vh^T Pl^T + Vl^T Ph^T + Vh^T Ph^T
+// with fp32 accumulation.  Why: with one f16 plane a base-2 logit of magnitude 30 carries an absolute error of ~1e-2, i.e. 1 % on
+// the softmax weights — invisible while attention is diffuse (random-weight fixtures), 2e-2 in the matching scores once the logit
+// spread reaches 25 (recipe-D fixtures, DESIGN.md §1: QK^T alone 1.4e-2, P V alone 5e-3; split: 5e-5 / < 5e-4).  There is no cheaper
+// operand format with >= 17 bits on gfx950 (no xf32; fp32 MFMA runs at 1/16 of the f16 rate).
+// Structure = attn_dma_kernel: LDS-DMA tiles, two buffers, one barrier per tile, wave priority by progress, scores accumulated
+// from -m_run.  A buffer holds four 8 KB tiles (K hi, K lo, V^T hi, V^T lo): 64 KB per workgroup, two workgroups per CU, two
+// waves per SIMD (<= 256 VGPRs).  QT = 16-row query tiles per wave: 2 (128-row workgroups) or 1 for under-filled grids.
+template <int QT>
+__global__ __launch_bounds__(ATHREADS, 2) void attn_split_kernel(AttnArgs a) {
+    typedef TagF16 Tag;
+    typedef f16_t T;
+    constexpr int ABM = 64 * QT, ROWB = 128, TILEB = 64 * ROWB, BUFB = 4 * TILEB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int ntile = gridDim.x >> 2;
+    const int v = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = v / ntile;
+    const TileLoc t = locate_tile(a.rs, v - head * ntile, ABM);
+    const int qlen = a.rs.len[t.seg];
+    if (t.r0 >= qlen) return;
+    if (a.rs.active && !a.rs.active[t.pair]) return;
+    const int kvseg = a.cross ? (t.seg ^ 1) : t.seg;
+    const int kvlen = a.rs.len[kvseg];
+    const long long kvbase = seg_row_base(a.rs, kvseg);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, g = lane >> 4;
+    const long long R = a.R, PL = a.plane;
+    const T* Q = static_cast<const T*>(a.q);
+    const T* Kp = static_cast<const T*>(a.cross ? a.q : a.k);
+    const T* Vt = static_cast<const T*>(a.vt);
+
+    if (kvlen == 0) {  // ref :114-115: empty key set -> zeros
+        for (int i = tid; i < ABM * 16; i += ATHREADS) {
+            const int row = i >> 4, c4 = i & 15;
+            if (t.r0 + row < qlen) *reinterpret_cast<f32x4*>(a.ctx + (t.grow0 + row) * 256LL + head * 64 + c4 * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
+
+    // DMA source offsets (elements), per lane: piece p = 2 * wave + i covers rows 8p .. 8p + 7 of each of the four tiles
+    const int prow = lane >> 3, pslot = lane & 7;
+    int koff[2], voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (2 * wave + i) * 8 + prow;
+        koff[i] = row * 64 + ((pslot ^ (((row >> 1) & 1) | (((row >> 3) & 3) << 1))) << 3);          // inverse of k_off<128>
+        voff[i] = (pslot ^ ((row >> 1) & 7)) << 3;                                                      // inverse of lds_off<128>; + row * R below
+    }
+    const T* kseg = Kp + ((long long)head * R + kvbase) * 64;
+    const T* vrow[2] = {Vt + ((long long)head * 64 + (2 * wave) * 8 + prow) * R + kvbase + voff[0],
+                        Vt + ((long long)head * 64 + (2 * wave + 1) * 8 + prow) * R + kvbase + voff[1]};
+    auto dma_tile = [&](int buf, int kv0) {
+        char* bK = smem + buf * BUFB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const T* ks = kseg + (long long)kv0 * 64 + koff[i];
+            const T* vs = vrow[i] + kv0;
+            char* dst = bK + (2 * wave + i) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ks + PL), (__attribute__((address_space(3))) void*)(dst + TILEB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs, (__attribute__((address_space(3))) void*)(dst + 2 * TILEB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vs + PL), (__attribute__((address_space(3))) void*)(dst + 3 * TILEB), 16, 0, 0);
+        }
+    };
+    dma_tile(0, 0);
+
+    // LDS fragment offsets (see attn_dma_kernel): per k-chunk c one base for the K tiles and one for the V^T tiles
+    int kfo[2], vfo[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        kfo[c] = k_off<ROWB>(8 * (lr >> 2) + (lr & 3), c * 4 + g);
+        vfo[c] = 2 * TILEB + lds_off<ROWB>(lr, 4 * c + g);
+    }
+    u32x4 qh[QT][2], ql[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const long long grow = (long long)t.grow0 + wave * (16 * QT) + qt * 16 + lr;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const T* src = Q + ((long long)head * R + grow) * 64 + c * 32 + g * 8;
+            qh[qt][c] = *reinterpret_cast<const u32x4*>(src);
+            ql[qt][c] = *reinterpret_cast<const u32x4*>(src + PL);
+        }
+    }
+    f32x4 o[4][QT];
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        m_run[qt] = 0.f; l_run[qt] = 0.f;          // finite: the accumulators start at -m_run; the first tile always re-bases (below)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int ntiles = (kvlen + ABK - 1) / ABK;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int kv0 = tile * ABK;
+        const char* bK = smem + (tile & 1) * BUFB;
+        if ((tile & 3) == 0) {   // wave priority by progress, see attn_dma_kernel
+            const int q = (tile * 4) / ntiles;
+            if (q == 0) __builtin_amdgcn_s_setprio(3); else if (q == 1) __builtin_amdgcn_s_setprio(2); else if (q == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of this tile (and, first time round, my Q fragments)
+        __syncthreads();
+        if (kv0 + ABK > kvlen) {                            // workgroup-uniform: zero the dead key columns of both V^T planes
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = tid + ATHREADS * (i & 1), row = c >> 3, slot = c & 7;
+                u32x4* p = reinterpret_cast<u32x4*>(const_cast<char*>(bK) + (2 + (i >> 1)) * TILEB + lds_off<ROWB>(row, slot));
+                *p = mask_tail<Tag>(*p, kvlen - (kv0 + slot * 8));
+            }
+            __syncthreads();
+        }
+        if (tile + 1 < ntiles) dma_tile((tile + 1) & 1, kv0 + ABK);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- S^T - m_run: per k-chunk and pair of key tiles, three products over 2 x QT independent accumulators
+        f32x4 s[4][QT];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{-m_run[qt], -m_run[qt], -m_run[qt], -m_run[qt]};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                u32x4 kh[2], kl[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int kt = 2 * kp + j;
+                    const char* src = bK + kfo[c] + (32 * (kt >> 1) + 4 * (kt & 1)) * ROWB;   // key row 32 (kt >> 1) + 8 (lr >> 2) + 4 (kt & 1) + (lr & 3)
+                    kh[j] = *reinterpret_cast<const u32x4*>(src);
+                    kl[j] = *reinterpret_cast<const u32x4*>(src + TILEB);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(s[2 * kp + j][qt], kh[j], ql[qt][c]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(s[2 * kp + j][qt], kl[j], qh[qt][c]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(s[2 * kp + j][qt], kh[j], qh[qt][c]);
+            }
+        }
+        if (kv0 + ABK > kvlen) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kv0 + 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r >= kvlen) s[kt][qt][r] = -INFINITY;
+        }
+        // ---- online softmax on d = score - m_run (deferred rescale; the first tile always re-bases), as in attn_dma_kernel
+        float dmax[QT];
+        bool grew = tile == 0;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const float t0 = vmax3(s[0][qt][0], s[0][qt][1], s[0][qt][2]), t1 = vmax3(s[0][qt][3], s[1][qt][0], s[1][qt][1]);
+            const float t2 = vmax3(s[1][qt][2], s[1][qt][3], s[2][qt][0]), t3 = vmax3(s[2][qt][1], s[2][qt][2], s[2][qt][3]);
+            const float t4 = vmax3(s[3][qt][0], s[3][qt][1], s[3][qt][2]);
+            float mx = vmax2(vmax3(t0, t1, t2), vmax3(t3, t4, s[3][qt][3]));
+            dmax[qt] = xor32_max(xor16_max(mx));              // finite: every tile holds >= 1 live key
+            grew = grew || (dmax[qt] > 8.f);
+        }
+        if (__any(grew)) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const float shift = tile == 0 ? dmax[qt] : vmax2(dmax[qt], 0.f);
+                const float alpha = tile == 0 ? 0.f : __builtin_amdgcn_exp2f(-shift);
+                l_run[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt][qt] *= alpha;
+                m_run[qt] += shift;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) s[kt][qt] -= shift;
+            }
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float rs0 = 0.f, rs1 = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const float p0 = __builtin_amdgcn_exp2f(s[kt][qt][0]), p1 = __builtin_amdgcn_exp2f(s[kt][qt][1]);
+                const float p2 = __builtin_amdgcn_exp2f(s[kt][qt][2]), p3 = __builtin_amdgcn_exp2f(s[kt][qt][3]);
+                s[kt][qt][0] = p0; s[kt][qt][1] = p1; s[kt][qt][2] = p2; s[kt][qt][3] = p3;
+                rs0 += p0 + p2; rs1 += p1 + p3;
+            }
+            l_run[qt] += rs0 + rs1;
+        }
+        // ---- O^T += V^T P^T with P = Ph + Pl (both f16; the residual p - Ph is exact in fp32): three products per (d tile, query tile)
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {
+            u32x4 ph[QT], pl[QT];
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) split8_f16<true>(s[2 * tp][qt], s[2 * tp + 1][qt], ph[qt], pl[qt]);
+#pragma unroll
+            for (int dp = 0; dp < 2; ++dp) {
+                u32x4 vh[2], vl[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const char* src = bK + vfo[tp] + (2 * dp + j) * 16 * ROWB;
+                    vh[j] = *reinterpret_cast<const u32x4*>(src);
+                    vl[j] = *reinterpret_cast<const u32x4*>(src + TILEB);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(o[2 * dp + j][qt], vh[j], pl[qt]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(o[2 * dp + j][qt], vl[j], ph[qt]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(o[2 * dp + j][qt], vh[j], ph[qt]);
+            }
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float l = l_run[qt];
+        l = xor32_sum(xor16_sum(l));
+        const float inv = 1.f / l;
+        const int qrow = t.r0 + wave * (16 * QT) + qt * 16 + lr;
+        if (qrow < qlen) {
+            float* dst = a.ctx + (t.grow0 + wave * (16 * QT) + qt * 16 + lr) * 256LL + head * 64 + g * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(dst + dt * 16) = o[dt][qt] * inv;
+        }
+    }
+}
+
+template <int QT> static hipError_t launch_attn_split(const AttnArgs& a, hipStream_t s) {
+    if (a.plane <= 0) return hipErrorInvalidValue;
+    constexpr int smem = 2 * 4 * 64 * 128;
+    auto kern = attn_split_kernel<QT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    const int tiles = a.rs.B * (a.rs.cap0 + a.rs.cap1) / (64 * QT);
+    hipLaunchKernelGGL(kern, dim3(tiles * 4), dim3(ATHREADS), smem, s, a);
+    return hipGetLastError();
+}
+
 template <class Tag> static hipError_t launch_attn_dma(const AttnArgs& a, hipStream_t s) {
     const int tiles = a.rs.B * (a.rs.cap0 + a.rs.cap1) / 128;
     hipLaunchKernelGGL((attn_dma_kernel<Tag>), dim3(tiles * 4), dim3(ATHREADS), 2 * 2 * 64 * 128, s, a);
@@ -626,6 +815,7 @@ hipError_t launch_attention(int attn_prec, const AttnArgs& a, hipStream_t s) {
         case PREC_F32: return launch_attn_t<TagF32, 2>(a, s);
         case PREC_BF16: if (a.dma && rpw == 32) return launch_attn_dma<TagBF16>(a, s); return rpw == 64 ? launch_attn_t<TagBF16, 4>(a, s) : rpw == 16 ? launch_attn_t<TagBF16, 1>(a, s) : launch_attn_t<TagBF16, 2>(a, s);
         case PREC_F16: if (a.dma && rpw == 32) return launch_attn_dma<TagF16>(a, s); return rpw == 64 ? launch_attn_t<TagF16, 4>(a, s) : rpw == 16 ? launch_attn_t<TagF16, 1>(a, s) : launch_attn_t<TagF16, 2>(a, s);
+        case PREC_F16X3: return rpw == 16 ? launch_attn_split<1>(a, s) : launch_attn_split<2>(a, s);
     }
     return hipErrorInvalidValue;
 }

@@ -32,12 +32,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // Operand precision of a contraction (host enum mirrored in include/lightglue_amd.h)
-enum : int { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2, PREC_BF16X3 = 3, PREC_F16X3 = 4 };
-// PREC_F16X3 (opt-in, NOT yet validated on the GPU): the split scheme of PREC_BF16X3 on f16 planes — same three MFMAs and bytes per
-// product; hi carries 11 bits instead of 8, so the dropped lo*lo term and the lo rounding are 2^-24-class instead of 2^-17-class
-// (emulated product error 3.5e-9 vs 3.6e-7 of sum |x||w|, tools/study_product_error.py).  Needs |x| < 65504 (the reference's own
-// fp16 mode needs the same).
-__host__ __device__ constexpr bool prec_is_split(int prec) { return prec == PREC_BF16X3 || prec == PREC_F16X3; }
+// (3 was split-bf16, the default of rounds 1-2: same cost as PREC_F16X3, 3x its score error on the GPU — removed in round 3)
+enum : int { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2, PREC_F16X3 = 4 };
+// PREC_F16X3: x = hi + lo with both planes f16, three MFMAs per product (hi*lo + lo*hi + hi*hi), fp32 accumulate: 22 operand bits;
+// the dropped lo*lo term and the lo rounding are 2^-24-class (product error 3.5e-9 of sum |x||w|).  Needs |x| < 65504 (the
+// reference's own fp16 mode needs the same); lo planes of small values live in f16 subnormals, which the MFMA honours.
+__host__ __device__ constexpr bool prec_is_split(int prec) { return prec == PREC_F16X3; }
 
 // Element tags
 struct TagF32 { typedef float elem; static constexpr int EPC = 4; };   // elements per 16-byte chunk
@@ -75,8 +75,6 @@ template <class Tag> __device__ __forceinline__ uint32_t pack2(float a, float b)
 template <> __device__ __forceinline__ uint32_t pack2<TagBF16>(float a, float b) { return pack2_bf16(a, b); }
 template <> __device__ __forceinline__ uint32_t pack2<TagF16>(float a, float b) { return pack2_f16(a, b); }
 
-__device__ __forceinline__ float bf16_round(float x) { return (float)(bf16_t)x; }
-
 // 8 floats -> one chunk of a 16-bit operand
 template <class Tag> __device__ __forceinline__ u32x4 pack8(const f32x4& lo, const f32x4& hi) {
     u32x4 r;
@@ -84,26 +82,37 @@ template <class Tag> __device__ __forceinline__ u32x4 pack8(const f32x4& lo, con
     r[2] = pack2<Tag>(hi[0], hi[1]); r[3] = pack2<Tag>(hi[2], hi[3]);
     return r;
 }
-// split-bf16: x = hi + lo (+ O(2^-17 x)); both halves bf16
-__device__ __forceinline__ void split8_bf16(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
-    float h[8], l[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { h[i] = bf16_round(a[i]); l[i] = a[i] - h[i]; h[4 + i] = bf16_round(b[i]); l[4 + i] = b[i] - h[4 + i]; }
-    hi[0] = pack2_bf16(h[0], h[1]); hi[1] = pack2_bf16(h[2], h[3]); hi[2] = pack2_bf16(h[4], h[5]); hi[3] = pack2_bf16(h[6], h[7]);
-    lo[0] = pack2_bf16(l[0], l[1]); lo[1] = pack2_bf16(l[2], l[3]); lo[2] = pack2_bf16(l[4], l[5]); lo[3] = pack2_bf16(l[6], l[7]);
+// split-f16: x = hi + lo, both f16 (lo of small values lives in f16 subnormals, which the MFMA honours).
+// Two values at a time in 4 instructions: v_cvt_pk_f16_f32 (hi pair), two v_fma_mix_f32 that read one half of the packed hi register
+// as f16 and return p - hi in fp32 (exact: the difference is representable), v_cvt_pk_f16_f32 (lo pair).  hipcc's own lowering of
+// the same expression is 8 instructions (v_cvt_f16_f32 x2, v_cvt_f32_f16 x2, v_sub x2, two packs).  The mix instructions read `hi`,
+// so they are always at least two instructions behind whatever produced a / b (no transcendental-result hazard can reach them).
+__device__ __forceinline__ void split2_f16(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = pack2_f16(a, b);
+    float la, lb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(la) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hi), "v"(b));
+    lo = pack2_f16(la, lb);
 }
-
-// split-f16: x = hi + lo, both f16 (lo of small values lives in f16 subnormals, which the MFMA honours)
+// 8 values -> one chunk of each plane.  MIX = false leaves the lowering to hipcc: in the fused tail's prologue (x / ctx rows ->
+// LDS, 250 live VGPRs) the asm form's operand constraints cost 4-6 spilled registers.
+template <bool MIX = true>
 __device__ __forceinline__ void split8_f16(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
-    float h[8], l[8];
+    if constexpr (MIX) {
+        uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+        split2_f16(a[0], a[1], h0, l0); split2_f16(a[2], a[3], h1, l1);
+        split2_f16(b[0], b[1], h2, l2); split2_f16(b[2], b[3], h3, l3);
+        hi = u32x4{h0, h1, h2, h3}; lo = u32x4{l0, l1, l2, l3};
+    } else {
+        float h[8], l[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { h[i] = (float)(f16_t)a[i]; l[i] = a[i] - h[i]; h[4 + i] = (float)(f16_t)b[i]; l[4 + i] = b[i] - h[4 + i]; }
-    hi[0] = pack2_f16(h[0], h[1]); hi[1] = pack2_f16(h[2], h[3]); hi[2] = pack2_f16(h[4], h[5]); hi[3] = pack2_f16(h[6], h[7]);
-    lo[0] = pack2_f16(l[0], l[1]); lo[1] = pack2_f16(l[2], l[3]); lo[2] = pack2_f16(l[4], l[5]); lo[3] = pack2_f16(l[6], l[7]);
+        for (int i = 0; i < 4; ++i) { h[i] = (float)(f16_t)a[i]; l[i] = a[i] - h[i]; h[4 + i] = (float)(f16_t)b[i]; l[4 + i] = b[i] - h[4 + i]; }
+        hi[0] = pack2_f16(h[0], h[1]); hi[1] = pack2_f16(h[2], h[3]); hi[2] = pack2_f16(h[4], h[5]); hi[3] = pack2_f16(h[6], h[7]);
+        lo[0] = pack2_f16(l[0], l[1]); lo[1] = pack2_f16(l[2], l[3]); lo[2] = pack2_f16(l[4], l[5]); lo[3] = pack2_f16(l[6], l[7]);
+    }
 }
 template <class Tag> __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo);
-template <> __device__ __forceinline__ void split8<TagBF16>(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) { split8_bf16(a, b, hi, lo); }
-template <> __device__ __forceinline__ void split8<TagF16>(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) { split8_f16(a, b, hi, lo); }
+template <> __device__ __forceinline__ void split8<TagF16>(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) { split8_f16<false>(a, b, hi, lo); }
 
 // ---- LDS tile addressing.  A tile is [rows][ROWB bytes] with ROWB = 128 or 256; the 16-byte
 // slot index within a row is XOR-swizzled with a function of the row so that the 16-lane groups of

@@ -93,7 +93,7 @@ struct lg_engine {
     bool weights_ready = false;
     // ---- device weights (layer-major arrays)
     void* w_arena = nullptr;
-    PackedW w_in, w_sqkv, w_sout, w_sf1, w_sf2, w_cqkv, w_cout, w_cf1, w_cf2, w_final;
+    PackedW w_in, w_sout, w_sf1, w_sf2, w_cout, w_cf1, w_cf2, w_final;
     float *b_in = nullptr, *b_sqkv = nullptr, *b_sout = nullptr, *b_sf1 = nullptr, *b_sf2 = nullptr, *b_cqkv = nullptr,
           *b_cout = nullptr, *b_cf1 = nullptr, *b_cf2 = nullptr, *b_final = nullptr;
     float *ln_s_g = nullptr, *ln_s_b = nullptr, *ln_c_g = nullptr, *ln_c_b = nullptr;  // [L][512]
@@ -103,20 +103,14 @@ struct lg_engine {
     char *w_stail_cat = nullptr, *w_stail_2 = nullptr, *w_ctail_cat = nullptr, *w_ctail_2 = nullptr;
     float *b_scat = nullptr, *b_ccat = nullptr;
     size_t tail_cat_layer_bytes = 0, tail_2_layer_bytes = 0;
-#ifdef LG_EXPERIMENTS
-    // ctx-half experiment (lg_tail.hip LG_TAIL_CTX_FP6, precision f16x3): per (block type, layer) the ctx half of Wcat as f16
-    // fragments in block-consecutive k order + hi scales (CTX16_BYTES) and fp6 lo records (CTX6_BYTES); own allocation
-    char *w_ctx16 = nullptr, *w_ctx6 = nullptr;
-#endif
     char *w_sqkv_p = nullptr, *w_cqkv_p = nullptr;   // fragment-packed projection weights (lg_proj.hip)
     size_t sqkv_layer_bytes = 0, cqkv_layer_bytes = 0;
     bool attn_dma = true;   // option "attn_dma": LDS-DMA attention kernel (16-bit operands, 32 rows per wave)
     int attn_rows = 32;   // query rows per attention wave (32 | 64), option "attn_rows" / env LG_ATTN_ROWS
-    int fused_tail = 1, fused_proj = 1, fused_next = 1, tail_variant = 0;   // tail_variant != 0: experiment builds only (lg_tail4.hip)
+    int fused_tail = 1, fused_next = 1;
     int tail_timing = 0; long long* TAILDBG = nullptr;
     int tail_row_tiles = 0;   // option "tail_row_tiles": 16-row tiles per fused-tail workgroup; 0 = by grid fill (4 | 2 | 1)
     bool attn_auto_rows = true;   // small grids: 16 query rows per attention wave (twice the workgroups); off once "attn_rows" is set
-    int tail_rows = 0;   // 0 = automatic, 64 / 128 = force the fused tail's rows per workgroup (option "tail_rows")
     // ---- workspace
     void* ws = nullptr; size_t ws_bytes = 0;
     int capB = 0, cap0 = 0, cap1 = 0;      // reserved
@@ -140,40 +134,34 @@ struct lg_engine {
 namespace {
 
 size_t elem_size(int prec) { return prec == PREC_F32 ? 4 : 2; }
+// bytes per element of the q / k / v^T buffers: the split attention keeps an f16 hi and an f16 lo plane
+size_t attn_elem_bytes(int attn_prec) { return attn_prec == PREC_F32 ? 4 : attn_prec == PREC_F16X3 ? 4 : 2; }
 
-// pack a [rows][K] fp32 host matrix into operand precision at device memory
+// pack a [rows][K] fp32 host matrix into operand precision at device memory (split f16: hi and lo planes)
 int upload_packed(int prec, const float* src, size_t n, PackedW& dst, size_t elem_offset) {
     const size_t es = elem_size(prec);
     std::vector<char> hi(n * es), lo;
     if (prec == PREC_F32) std::memcpy(hi.data(), src, n * 4);
-    else if (prec == PREC_F16) { auto* p = reinterpret_cast<uint16_t*>(hi.data()); for (size_t i = 0; i < n; ++i) p[i] = f32_to_f16(src[i]); }
+    else if (prec == PREC_BF16) { auto* p = reinterpret_cast<uint16_t*>(hi.data()); for (size_t i = 0; i < n; ++i) p[i] = f32_to_bf16(src[i]); }
     else {
         auto* p = reinterpret_cast<uint16_t*>(hi.data());
-        for (size_t i = 0; i < n; ++i) p[i] = f32_to_bf16(src[i]);
-        if (prec == PREC_BF16X3) {
+        for (size_t i = 0; i < n; ++i) p[i] = f32_to_f16(src[i]);
+        if (prec == PREC_F16X3) {
             lo.resize(n * es);
             auto* q = reinterpret_cast<uint16_t*>(lo.data());
-            for (size_t i = 0; i < n; ++i) q[i] = f32_to_bf16(src[i] - bf16_to_f32(p[i]));
+            for (size_t i = 0; i < n; ++i) q[i] = f32_to_f16(src[i] - f16_to_f32(p[i]));
         }
-    }
-    if (prec == PREC_F16X3) {   // (the branch above wrote bf16: redo both planes in f16)
-        auto* p = reinterpret_cast<uint16_t*>(hi.data());
-        lo.resize(n * es);
-        auto* q = reinterpret_cast<uint16_t*>(lo.data());
-        for (size_t i = 0; i < n; ++i) { p[i] = f32_to_f16(src[i]); q[i] = f32_to_f16(src[i] - f16_to_f32(p[i])); }
     }
     HIPCHK(hipMemcpy(static_cast<char*>(dst.hi) + elem_offset * es, hi.data(), n * es, hipMemcpyHostToDevice));
     if (prec_is_split(prec)) HIPCHK(hipMemcpy(static_cast<char*>(dst.lo) + elem_offset * es, lo.data(), n * es, hipMemcpyHostToDevice));
     return LG_OK;
 }
 
-// MFMA-fragment order (lg_kernels.h TailArgs): plane-major, then [n-tile][k-chunk][lane][EPC]
-// split_f16: hi = f16(v), lo = f16(v - hi) planes (the q/k/v projection weights of the default precision, lg_proj_body.h)
-int upload_fragment_packed(int prec, const std::vector<double>& W, int rows, int K, char* dst, bool split_f16 = false) {
+// MFMA-fragment order (lg_kernels.h TailArgs): plane-major, then [n-tile][k-chunk][lane][EPC]; split f16: hi = f16(v), lo = f16(v - hi)
+int upload_fragment_packed(int prec, const std::vector<double>& W, int rows, int K, char* dst) {
     const size_t es = elem_size(prec);
     const int EPC = prec == PREC_F32 ? 4 : 8, KC = 4 * EPC, NKC = K / KC, NT = rows / 16;
     const bool split = prec_is_split(prec);
-    if (prec == PREC_F16X3) split_f16 = true;   // both planes f16
     const size_t n = (size_t)rows * K;
     std::vector<char> buf(n * es * (split ? 2 : 1));
     for (int nt = 0; nt < NT; ++nt)
@@ -183,81 +171,16 @@ int upload_fragment_packed(int prec, const std::vector<double>& W, int rows, int
                     const float v = (float)W[(size_t)(nt * 16 + (lane & 15)) * K + kc * KC + (lane >> 4) * EPC + j];
                     const size_t idx = ((size_t)(nt * NKC + kc) * 64 + lane) * EPC + j;
                     if (prec == PREC_F32) reinterpret_cast<float*>(buf.data())[idx] = v;
-                    else if (prec == PREC_F16) reinterpret_cast<uint16_t*>(buf.data())[idx] = f32_to_f16(v);
-                    else if (split_f16) {
+                    else if (prec == PREC_BF16) reinterpret_cast<uint16_t*>(buf.data())[idx] = f32_to_bf16(v);
+                    else {
                         const uint16_t h = f32_to_f16(v);
                         reinterpret_cast<uint16_t*>(buf.data())[idx] = h;
-                        reinterpret_cast<uint16_t*>(buf.data())[n + idx] = f32_to_f16(v - f16_to_f32(h));
-                    } else {
-                        const uint16_t h = f32_to_bf16(v);
-                        reinterpret_cast<uint16_t*>(buf.data())[idx] = h;
-                        if (split) reinterpret_cast<uint16_t*>(buf.data())[n + idx] = f32_to_bf16(v - bf16_to_f32(h));
+                        if (split) reinterpret_cast<uint16_t*>(buf.data())[n + idx] = f32_to_f16(v - f16_to_f32(h));
                     }
                 }
     HIPCHK(hipMemcpy(dst, buf.data(), buf.size(), hipMemcpyHostToDevice));
     return LG_OK;
 }
-
-#ifdef LG_EXPERIMENTS
-constexpr size_t CTX16_FRAG_BYTES = (size_t)32 * 2 * 4 * 64 * 16, CTX16_BYTES = CTX16_FRAG_BYTES + (size_t)32 * 2 * 64 * 4, CTX6_BYTES = (size_t)32 * 2 * 64 * 32;
-// fp6 e2m3 code (sign, 2 exponent bits with bias 1, 3 mantissa bits; subnormal step 0.125) of v, round to nearest even, saturating at 7.5
-unsigned fp6_e2m3_code(float v) {
-    const unsigned sign = std::signbit(v) ? 32u : 0u;
-    const float a = std::fabs(v);
-    if (!(a < 7.75f)) return sign | 31u;                       // saturate (also NaN)
-    if (a < 1.0f) {                                            // subnormal range, step 0.125; 8 steps = 1.0 = (e 1, m 0)
-        const int m = (int)std::nearbyint(a * 8.0f);
-        return sign | (m == 8 ? 8u : (unsigned)m);
-    }
-    int e = a < 2.0f ? 0 : (a < 4.0f ? 1 : 2);                // value = (1 + m/8) 2^e
-    int m = (int)std::nearbyint(std::ldexp(a, 3 - e));         // 8 .. 16
-    if (m == 16) { m = 8; ++e; }
-    if (e > 2) return sign | 31u;
-    return sign | ((unsigned)(e + 1) << 3) | (unsigned)(m - 8);
-}
-// smallest E8M0 byte with amax / 2^(byte - 127) <= 7.5 — the same rule as the kernel's e8m0_for
-int e8m0_for_host(float amax) {
-    if (amax == 0.f) return 127;
-    const float t = amax * (16.f / 15.f);
-    uint32_t u; std::memcpy(&u, &t, 4);
-    const int e = (int)((u >> 23) & 0xFF) - 2;
-    return e < 1 ? 1 : e;
-}
-// one MX block of 32 weights -> f16 hi halves, the hi block's scale, 24 bytes of fp6 lo codes (slot i at bits [6i, 6i+6)) and their scale
-void split_block_fp6(const float* v, uint16_t* h16, int& sh, uint32_t* lo6, int& sl) {
-    float hf[32], l[32], ah = 0.f, al = 0.f;
-    for (int i = 0; i < 32; ++i) {
-        h16[i] = f32_to_f16(v[i]); hf[i] = f16_to_f32(h16[i]); l[i] = v[i] - hf[i];
-        ah = std::fmax(ah, std::fabs(hf[i])); al = std::fmax(al, std::fabs(l[i]));
-    }
-    sh = e8m0_for_host(ah); sl = e8m0_for_host(al);
-    for (int i = 0; i < 6; ++i) lo6[i] = 0;
-    for (int i = 0; i < 32; ++i) {
-        const uint64_t code = fp6_e2m3_code(std::ldexp(l[i], 127 - sl));
-        const int bit = 6 * i, wd = bit >> 5, sft = bit & 31;
-        lo6[wd] |= (uint32_t)(code << sft);
-        if (sft > 26) lo6[wd + 1] |= (uint32_t)(code >> (32 - sft));
-    }
-}
-// the ctx half (columns 256..511) of a folded [512][512] ffn.0 matrix in the layout lg_tail.hip's ctx-half experiment reads
-void pack_ctx6(const std::vector<double>& cat, std::vector<char>& w16, std::vector<char>& w6) {
-    w16.assign(CTX16_BYTES, 0); w6.assign(CTX6_BYTES, 0);
-    for (int nt = 0; nt < 32; ++nt)
-        for (int c = 0; c < 2; ++c)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int lr = lane & 15, g = lane >> 4;
-                float v[32]; uint16_t h16[32]; uint32_t lo6[6]; int sh, sl;
-                for (int i = 0; i < 32; ++i) v[i] = (float)cat[(size_t)(nt * 16 + lr) * 512 + 256 + 128 * c + 32 * g + i];
-                split_block_fp6(v, h16, sh, lo6, sl);
-                const size_t base = (size_t)nt * 2 + c;
-                for (int q = 0; q < 4; ++q) std::memcpy(&w16[((base * 4 + q) * 64 + lane) * 16], &h16[8 * q], 16);
-                const uint32_t shd = (uint32_t)sh * 0x01010101u, sld = (uint32_t)sl * 0x01010101u;
-                std::memcpy(&w16[CTX16_FRAG_BYTES + (base * 64 + lane) * 4], &shd, 4);
-                uint32_t rec[8] = {lo6[0], lo6[1], lo6[2], lo6[3], lo6[4], lo6[5], sld, 0u};
-                std::memcpy(&w6[(base * 64 + lane) * 32], rec, 32);
-            }
-}
-#endif
 
 const HostTensor* find(const lg_engine* e, const std::string& name, std::initializer_list<int64_t> shape, std::string& err) {
     auto it = e->staged.find(name);
@@ -294,7 +217,7 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
         const int nB = B > e->capB ? B : e->capB, nc0 = c0 > e->cap0 ? c0 : e->cap0, nc1 = c1 > e->cap1 ? c1 : e->cap1;
         if (e->ws) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(e->ws)); e->ws = nullptr; }
         e->capB = nB; e->cap0 = nc0; e->cap1 = nc1;
-        const size_t R = (size_t)nB * (nc0 + nc1), as = elem_size(e->attn_prec);
+        const size_t R = (size_t)nB * (nc0 + nc1), as = attn_elem_bytes(e->attn_prec);
         size_t total = 0;
         auto add = [&](size_t b) { total = ((total + 255) & ~size_t(255)) + b; };
         for (int i = 0; i < 3; ++i) add(R * 256 * 4);           // X CTX MSG
@@ -321,7 +244,7 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
     if (fits && e->curB == B && e->cur_cap0 == c0 && e->cur_cap1 == c1 && !e->bufs.empty()) return LG_OK;
     e->curB = B; e->cur_cap0 = c0; e->cur_cap1 = c1;
     DevArena ar{static_cast<char*>(e->ws), e->ws_bytes, 0};
-    const size_t R = (size_t)B * (c0 + c1), as = elem_size(e->attn_prec);
+    const size_t R = (size_t)B * (c0 + c1), as = attn_elem_bytes(e->attn_prec);
     e->bufs.clear();
     auto take = [&](const char* name, size_t bytes) { void* p = ar.take(bytes); e->bufs[name] = {p, bytes}; return p; };
     e->X = (float*)take("X", R * 256 * 4); e->CTX = (float*)take("CTX", R * 256 * 4); e->MSG = (float*)take("MSG", R * 256 * 4);
@@ -405,17 +328,14 @@ int lg_engine_create(const lg_config* cfg, lg_engine** out) {
     if (cfg->descriptor_dim != 256 || cfg->num_heads != 4) return fail(LG_ERR_INVALID, "only descriptor_dim=256, num_heads=4 (head_dim 64) are built");
     if (cfg->n_layers < 1 || cfg->n_layers > 64) return fail(LG_ERR_INVALID, "bad n_layers");
     if (cfg->input_dim <= 0 || cfg->input_dim % 64) return fail(LG_ERR_INVALID, "input_dim must be a positive multiple of 64");
-    if (cfg->precision < 0 || cfg->precision > LG_PREC_F16X3) return fail(LG_ERR_INVALID, "bad precision");
+    if (cfg->precision != LG_PREC_F32 && cfg->precision != LG_PREC_BF16 && cfg->precision != LG_PREC_F16 && cfg->precision != LG_PREC_F16X3) return fail(LG_ERR_INVALID, "bad precision");
     auto* e = new lg_engine();
     e->cfg = *cfg;
     int ap = cfg->attn_precision;
-    if (ap < 0) ap = prec_is_split(cfg->precision) ? PREC_F16 : cfg->precision;
-    if (ap != PREC_F32 && ap != PREC_BF16 && ap != PREC_F16) { delete e; return fail(LG_ERR_INVALID, "bad attn_precision"); }
+    if (ap < 0) ap = cfg->precision;   // f16x3 -> split attention; every other precision -> its own element type
+    // pairs with a q/k/v projection kernel (lg_proj.hip): a precision with itself, or f16x3 with one f16 plane (the fast opt-in)
+    if (!(ap == cfg->precision || (cfg->precision == PREC_F16X3 && ap == PREC_F16))) { delete e; return fail(LG_ERR_INVALID, "bad attn_precision: must equal `precision`, or LG_PREC_F16 with LG_PREC_F16X3"); }
     e->attn_prec = ap;
-#ifdef LG_EXPERIMENTS   // A/B switches of experiment builds (tools/build_variant.sh ... -DLG_EXPERIMENTS); the product reads no environment
-    if (const char* tv = std::getenv("LG_TAIL_VARIANT")) e->tail_variant = std::atoi(tv);
-    if (const char* ar = std::getenv("LG_ATTN_ROWS")) { const int v = std::atoi(ar); e->attn_rows = (v == 64 || v == 16) ? v : 32; }
-#endif
     *out = e;
     return LG_OK;
 }
@@ -425,10 +345,6 @@ void lg_engine_destroy(lg_engine* e) {
     for (auto& sp : e->prof_pool) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     if (e->ws) (void)hipFree(e->ws);
     if (e->w_arena) (void)hipFree(e->w_arena);
-#ifdef LG_EXPERIMENTS
-    if (e->w_ctx16) (void)hipFree(e->w_ctx16);
-    if (e->w_ctx6) (void)hipFree(e->w_ctx6);
-#endif
     delete e;
 }
 
@@ -454,8 +370,8 @@ int lg_engine_finalize_weights(lg_engine* e) {
     auto addw = [&](size_t elems) { total = ((total + 255) & ~size_t(255)) + elems * es; if (split) total = ((total + 255) & ~size_t(255)) + elems * es; };
     auto addf = [&](size_t n) { total = ((total + 255) & ~size_t(255)) + n * 4; };
     addw((size_t)D * Din);
-    addw((size_t)L * 768 * D); addw((size_t)L * D * D); addw((size_t)L * 512 * 512); addw((size_t)L * D * 512);
-    addw((size_t)L * 512 * D); addw((size_t)L * D * D); addw((size_t)L * 512 * 512); addw((size_t)L * D * 512);
+    addw((size_t)L * D * D); addw((size_t)L * 512 * 512); addw((size_t)L * D * 512);
+    addw((size_t)L * D * D); addw((size_t)L * 512 * 512); addw((size_t)L * D * 512);
     addw((size_t)L * D * D);
     addf(D); addf((size_t)L * 768); addf((size_t)L * D); addf((size_t)L * 512); addf((size_t)L * D);
     addf((size_t)L * 512); addf((size_t)L * D); addf((size_t)L * 512); addf((size_t)L * D); addf((size_t)L * D);
@@ -476,8 +392,8 @@ int lg_engine_finalize_weights(lg_engine* e) {
     auto takew = [&](PackedW& w, size_t elems) { w.hi = ar.take(elems * es); w.lo = split ? ar.take(elems * es) : nullptr; };
     auto takef = [&](size_t n) { return static_cast<float*>(ar.take(n * 4)); };
     takew(e->w_in, (size_t)D * Din);
-    takew(e->w_sqkv, (size_t)L * 768 * D); takew(e->w_sout, (size_t)L * D * D); takew(e->w_sf1, (size_t)L * 512 * 512); takew(e->w_sf2, (size_t)L * D * 512);
-    takew(e->w_cqkv, (size_t)L * 512 * D); takew(e->w_cout, (size_t)L * D * D); takew(e->w_cf1, (size_t)L * 512 * 512); takew(e->w_cf2, (size_t)L * D * 512);
+    takew(e->w_sout, (size_t)L * D * D); takew(e->w_sf1, (size_t)L * 512 * 512); takew(e->w_sf2, (size_t)L * D * 512);
+    takew(e->w_cout, (size_t)L * D * D); takew(e->w_cf1, (size_t)L * 512 * 512); takew(e->w_cf2, (size_t)L * D * 512);
     takew(e->w_final, (size_t)L * D * D);
     e->b_in = takef(D); e->b_sqkv = takef((size_t)L * 768); e->b_sout = takef((size_t)L * D); e->b_sf1 = takef((size_t)L * 512); e->b_sf2 = takef((size_t)L * D);
     e->b_cqkv = takef((size_t)L * 512); e->b_cout = takef((size_t)L * D); e->b_cf1 = takef((size_t)L * 512); e->b_cf2 = takef((size_t)L * D); e->b_final = takef((size_t)L * D);
@@ -513,8 +429,7 @@ int lg_engine_finalize_weights(lg_engine* e) {
                 std::memcpy(&pw[(size_t)dst * D], &w->data[(size_t)src * D], D * 4);
                 pb[dst] = b->data[src];
             }
-            TRY(upload_packed(prec, pw.data(), pw.size(), e->w_sqkv, (size_t)i * 768 * D));
-            TRY(upload_fragment_packed(prec, std::vector<double>(pw.begin(), pw.end()), 768, D, e->w_sqkv_p + (size_t)i * sqkv_layer, prec_is_split(prec)));
+            TRY(upload_fragment_packed(prec, std::vector<double>(pw.begin(), pw.end()), 768, D, e->w_sqkv_p + (size_t)i * sqkv_layer));
             TRY(up_f32(e->b_sqkv + (size_t)i * 768, pb.data(), 768));
         }
         {
@@ -556,15 +471,6 @@ int lg_engine_finalize_weights(lg_engine* e) {
             }
             for (size_t q = 0; q < w2d.size(); ++q) w2d[q] = w3->data[q];
             TRY(upload_fragment_packed(prec, cat, 512, 512, (blk ? e->w_ctail_cat : e->w_stail_cat) + (size_t)i * cat_layer));
-#ifdef LG_EXPERIMENTS
-            if (prec == PREC_F16X3) {
-                if (!e->w_ctx16) { HIPCHK(hipMalloc(&e->w_ctx16, 2 * (size_t)L * CTX16_BYTES)); HIPCHK(hipMalloc(&e->w_ctx6, 2 * (size_t)L * CTX6_BYTES)); }
-                std::vector<char> w16, w6;
-                pack_ctx6(cat, w16, w6);
-                HIPCHK(hipMemcpy(e->w_ctx16 + ((size_t)blk * L + i) * CTX16_BYTES, w16.data(), CTX16_BYTES, hipMemcpyHostToDevice));
-                HIPCHK(hipMemcpy(e->w_ctx6 + ((size_t)blk * L + i) * CTX6_BYTES, w6.data(), CTX6_BYTES, hipMemcpyHostToDevice));
-            }
-#endif
             TRY(upload_fragment_packed(prec, w2d, 256, 512, (blk ? e->w_ctail_2 : e->w_stail_2) + (size_t)i * w2_layer));
             TRY(up_f32((blk ? e->b_ccat : e->b_scat) + (size_t)i * 512, bc.data(), 512));
         }
@@ -576,8 +482,7 @@ int lg_engine_finalize_weights(lg_engine* e) {
             std::memcpy(pw.data(), wq->data.data(), (size_t)D * D * 4);
             std::memcpy(pw.data() + (size_t)D * D, wv->data.data(), (size_t)D * D * 4);
             std::memcpy(pb.data(), bq->data.data(), D * 4); std::memcpy(pb.data() + D, bv->data.data(), D * 4);
-            TRY(upload_packed(prec, pw.data(), pw.size(), e->w_cqkv, (size_t)i * 512 * D));
-            TRY(upload_fragment_packed(prec, std::vector<double>(pw.begin(), pw.end()), 512, D, e->w_cqkv_p + (size_t)i * cqkv_layer, prec_is_split(prec)));
+            TRY(upload_fragment_packed(prec, std::vector<double>(pw.begin(), pw.end()), 512, D, e->w_cqkv_p + (size_t)i * cqkv_layer));
             TRY(up_f32(e->b_cqkv + (size_t)i * 512, pb.data(), 512));
             TRY(upload_packed(prec, wo->data.data(), (size_t)D * D, e->w_cout, (size_t)i * D * D));
             TRY(up_f32(e->b_cout + (size_t)i * D, bo->data.data(), D));
@@ -611,18 +516,6 @@ int lg_engine_reserve(lg_engine* e, int32_t max_batch, int32_t max_n0, int32_t m
 int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
     if (!e || !key) return fail(LG_ERR_INVALID, "null argument");
     if (std::strcmp(key, "fused_tail") == 0) { e->fused_tail = value != 0; return LG_OK; }
-#ifdef LG_EXPERIMENTS
-    if (std::strcmp(key, "tail_variant") == 0) { e->tail_variant = value; return LG_OK; }
-#else
-    if (std::strcmp(key, "tail_variant") == 0) return value == 0 ? LG_OK : fail(LG_ERR_INVALID, "tail_variant: the streaming tail variants are experiment builds only (-DLG_EXPERIMENTS)");
-#endif
-#if defined(LG_ATTN_FOLD) && LG_ATTN_FOLD   // experiment build: only the fragment-packed projection pre-scales q and k (lg_proj_body.h)
-    if (std::strcmp(key, "fused_proj") == 0) { if (!value) return fail(LG_ERR_INVALID, "fused_proj = 0 is not available in LG_ATTN_FOLD builds"); return LG_OK; }
-#endif
-    if (std::strcmp(key, "fused_proj") == 0) { e->fused_proj = value != 0; return LG_OK; }
-#ifdef LG_EXPERIMENTS
-    if (std::strcmp(key, "tail_rows") == 0) { if (value != 0 && value != 64 && value != 128) return fail(LG_ERR_INVALID, "tail_rows must be 0, 64 or 128"); e->tail_rows = value; return LG_OK; }
-#endif
     if (std::strcmp(key, "fused_next") == 0) { e->fused_next = value != 0; return LG_OK; }
     if (std::strcmp(key, "attn_dma") == 0) { e->attn_dma = value != 0; return LG_OK; }
     if (std::strcmp(key, "attn_rows") == 0) { if (value != 16 && value != 32 && value != 64) return fail(LG_ERR_INVALID, "attn_rows must be 16, 32 or 64"); e->attn_rows = value; e->attn_auto_rows = false; return LG_OK; }
@@ -848,15 +741,15 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
     };
     if (e->cfg.input_dim != D) {  // ref :521-522
         GemmArgs g = gemm(EPI_STORE, rs_all, e->XIN, e->cfg.input_dim, nullptr, 0, e->cfg.input_dim, e->cfg.input_dim, e->w_in, e->b_in, D, e->X, D, 1.f);
-        HIPCHK(launch_gemm(prec, EPI_STORE, ap, g, s));
+        HIPCHK(launch_gemm(prec, EPI_STORE, g, s));
     }
     TRY(prof_end(e, s));
     STEP_DONE();
-    const float scale_log2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+    const long long qkv_plane = ap == PREC_F16X3 ? (long long)R * 256 : 0;   // split attention: hi plane, then lo plane, of q / k / v^T
 
     auto make_proj = [&](int layer, int blk) {   // q/k/v projection of block `blk` of `layer` (lg_proj.hip / fused into lg_tail.hip)
         ProjArgs pj{};
-        pj.rs = rs_act; pj.X = e->X; pj.R = R; pj.q = e->Q; pj.k = e->K; pj.vt = e->VT;
+        pj.rs = rs_act; pj.X = e->X; pj.R = R; pj.q = e->Q; pj.k = e->K; pj.vt = e->VT; pj.plane = qkv_plane;
         pj.W = blk == 0 ? e->w_sqkv_p + (size_t)layer * e->sqkv_layer_bytes : e->w_cqkv_p + (size_t)layer * e->cqkv_layer_bytes;
         pj.bias = blk == 0 ? e->b_sqkv + (size_t)layer * 768 : e->b_cqkv + (size_t)layer * 512;
         pj.Nout = blk == 0 ? 768 : 512; pj.n_qk_groups = blk == 0 ? 2 : 1;
@@ -866,35 +759,24 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
     };
     // fused_next: a tail kernel also runs the NEXT block's projection on the x tile it has just produced.  Across a
     // layer boundary that is only valid when nothing re-orders rows in between (no early stop / pruning step).
-    const bool fuse_next = e->fused_next && e->fused_tail && e->fused_proj && e->tail_variant == 0 && e->tail_timing == 0 &&
+    const bool fuse_next = e->fused_next && e->fused_tail && e->tail_timing == 0 &&
                            e->debug_stop < 0 && launch_tail_supports_next(prec, ap);
     const bool prune_possible = do_prune && (n0 > e->cfg.pruning_min_kpts || n1 > e->cfg.pruning_min_kpts);
     bool proj_done = false;
     for (int i = 0; i < L; ++i) {
         for (int blk = 0; blk < 2; ++blk) {  // 0 = SelfBlock (ref :159-172), 1 = CrossBlock (ref :201-230)
-            if (e->fused_proj) {
-                if (!proj_done) {   // otherwise the previous block's tail kernel has already produced q/k/v (fused_next)
-                    ProjArgs pj = make_proj(i, blk);
-                    pj.dbg = (e->tail_timing == 2 && blk == 0) ? e->TAILDBG : nullptr;
-                    TRY(prof_begin(e, blk == 0 ? PC_GEMM_QKV_SELF : PC_GEMM_QKV_CROSS, s));
-                    HIPCHK(launch_proj(prec, ap, pj, s));
-                    TRY(prof_end(e, s));
-                }
-                proj_done = false;
-            } else
-            {
-                GemmArgs g = blk == 0 ? gemm(EPI_QKV, rs_act, e->X, D, nullptr, 0, D, D, woff(e->w_sqkv, (size_t)i * 768 * D), e->b_sqkv + (size_t)i * 768, 768, nullptr, 0, 1.f)
-                                      : gemm(EPI_QKV, rs_act, e->X, D, nullptr, 0, D, D, woff(e->w_cqkv, (size_t)i * 512 * D), e->b_cqkv + (size_t)i * 512, 512, nullptr, 0, 1.f);
-                g.q = e->Q; g.k = e->K; g.vt = e->VT; g.n_qk_groups = blk == 0 ? 2 : 1;
-                g.cosb = blk == 0 ? e->COS : nullptr; g.sinb = blk == 0 ? e->SIN : nullptr;
+            if (!proj_done) {   // otherwise the previous block's tail kernel has already produced q/k/v (fused_next)
+                ProjArgs pj = make_proj(i, blk);
+                pj.dbg = (e->tail_timing == 2 && blk == 0) ? e->TAILDBG : nullptr;
                 TRY(prof_begin(e, blk == 0 ? PC_GEMM_QKV_SELF : PC_GEMM_QKV_CROSS, s));
-                HIPCHK(launch_gemm(prec, EPI_QKV, ap, g, s));
+                HIPCHK(launch_proj(prec, ap, pj, s));
                 TRY(prof_end(e, s));
             }
+            proj_done = false;
             STEP_DONE();
             {
                 AttnArgs at{};
-                at.rs = rs_act; at.q = e->Q; at.k = e->K; at.vt = e->VT; at.ctx = e->CTX; at.R = R; at.cross = blk; at.scale_log2e = scale_log2e;
+                at.rs = rs_act; at.q = e->Q; at.k = e->K; at.vt = e->VT; at.plane = qkv_plane; at.ctx = e->CTX; at.R = R; at.cross = blk;
                 at.dbg = (e->tail_timing == 3 && blk == 0) ? e->TAILDBG : nullptr;
                 at.rows_per_wave = (e->attn_auto_rows && R / 128 * 4 < 256) ? 16 : e->attn_rows; at.dma = e->attn_dma ? 1 : 0;   // fewer 128-row workgroups than CUs: 64-row ones
                 TRY(prof_begin(e, blk == 0 ? PC_ATTN_SELF : PC_ATTN_CROSS, s));
@@ -910,9 +792,6 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 ta.gamma = (blk ? e->ln_c_g : e->ln_s_g) + (size_t)i * 512; ta.beta = (blk ? e->ln_c_b : e->ln_s_b) + (size_t)i * 512;
                 ta.W2 = (blk ? e->w_ctail_2 : e->w_stail_2) + (size_t)i * e->tail_2_layer_bytes;
                 ta.b2 = (blk ? e->b_cf2 : e->b_sf2) + (size_t)i * D;
-#ifdef LG_EXPERIMENTS
-                if (e->w_ctx16) { ta.Wc16 = e->w_ctx16 + ((size_t)blk * L + i) * CTX16_BYTES; ta.Wc6 = e->w_ctx6 + ((size_t)blk * L + i) * CTX6_BYTES; }
-#endif
                 ta.dbg = e->tail_timing == 1 ? e->TAILDBG : nullptr;
                 ta.row_tiles = e->tail_row_tiles ? e->tail_row_tiles : tail_row_tiles_for(R);
                 // Across a layer boundary the fusion is valid whenever no row can MOVE in between: early stop alone only
@@ -923,12 +802,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                     proj_done = true;
                 }
                 TRY(prof_begin(e, PC_TAIL, s));
-#ifdef LG_EXPERIMENTS
-                if (e->tail_rows == 128 && prec == PREC_BF16X3 && ap == PREC_F16) HIPCHK(launch_tail_rows128(ta, s));   // lg_tail128.hip: +2 % time
-                else HIPCHK(e->tail_variant == 1 ? launch_tail4(prec, ta, s) : e->tail_variant == 2 ? launch_tail128(prec, ta, s) : e->tail_variant == 3 ? launch_tail32(prec, ta, s) : launch_tail(prec, ap, ta, s));
-#else
                 HIPCHK(launch_tail(prec, ap, ta, s));
-#endif
                 TRY(prof_end(e, s));
                 STEP_DONE(); STEP_DONE(); STEP_DONE(); STEP_DONE();
                 continue;
@@ -937,7 +811,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 GemmArgs g = gemm(EPI_STORE, rs_act, e->CTX, D, nullptr, 0, D, D, woff(blk ? e->w_cout : e->w_sout, (size_t)i * D * D),
                                   (blk ? e->b_cout : e->b_sout) + (size_t)i * D, D, e->MSG, D, 1.f);
                 TRY(prof_begin(e, PC_GEMM_OUT, s));
-                HIPCHK(launch_gemm(prec, EPI_STORE, ap, g, s));
+                HIPCHK(launch_gemm(prec, EPI_STORE, g, s));
                 TRY(prof_end(e, s));
             }
             STEP_DONE();
@@ -945,7 +819,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 GemmArgs g = gemm(EPI_STORE, rs_act, e->X, D, e->MSG, D, D, 512, woff(blk ? e->w_cf1 : e->w_sf1, (size_t)i * 512 * 512),
                                   (blk ? e->b_cf1 : e->b_sf1) + (size_t)i * 512, 512, e->H1, 512, 1.f);
                 TRY(prof_begin(e, PC_GEMM_FFN1, s));
-                HIPCHK(launch_gemm(prec, EPI_STORE, ap, g, s));
+                HIPCHK(launch_gemm(prec, EPI_STORE, g, s));
                 TRY(prof_end(e, s));
             }
             STEP_DONE();
@@ -960,7 +834,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 GemmArgs g = gemm(EPI_RESID, rs_act, e->G, 512, nullptr, 0, 512, 512, woff(blk ? e->w_cf2 : e->w_sf2, (size_t)i * D * 512),
                                   (blk ? e->b_cf2 : e->b_sf2) + (size_t)i * D, D, e->X, D, 1.f);
                 TRY(prof_begin(e, PC_GEMM_FFN2, s));
-                HIPCHK(launch_gemm(prec, EPI_RESID, ap, g, s));
+                HIPCHK(launch_gemm(prec, EPI_RESID, g, s));
                 TRY(prof_end(e, s));
             }
             STEP_DONE();
@@ -1009,7 +883,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
         GemmArgs g = gemm(EPI_STORE, rs_all, e->X, D, nullptr, 0, D, D, e->w_final, e->b_final, D, e->MD, D, 0.25f);  // ref :291: / d**0.25
         g.layer_of_pair = e->FINAL_LAYER; g.w_layer_stride = (long long)D * D; g.b_layer_stride = D;
         TRY(prof_begin(e, PC_GEMM_FINAL, s));
-        HIPCHK(launch_gemm(prec, EPI_STORE, ap, g, s));
+        HIPCHK(launch_gemm(prec, EPI_STORE, g, s));
         TRY(prof_end(e, s));
         SimArgs sm{rs_all, e->MD, D, D, e->SIM};
         TRY(prof_begin(e, PC_SIM, s));
@@ -1033,26 +907,5 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
 #undef TRY
     return LG_OK;
 }
-
-#ifdef LG_EXPERIMENTS
-// experiment builds only (not in include/lightglue_amd.h): the host-side MX-block split of the ctx-half experiment, for a CPU test
-// against the numpy emulation (tests/test_fp6_packing.py).  v[32] -> h16[32] (f16 bits), *sh, lo6[6] (fp6 codes, slot i at bits [6i, 6i+6)), *sl
-int lg_debug_split_block_fp6(const float* v, uint16_t* h16, int32_t* sh, uint32_t* lo6, int32_t* sl) {
-    int a, b;
-    split_block_fp6(v, h16, a, lo6, b);
-    *sh = a; *sl = b;
-    return LG_OK;
-}
-// cat [512][512] (row-major, columns 256..511 = the ctx half) -> the two device buffers, on the host (sizes via the first call with null outputs)
-int lg_debug_pack_ctx6(const double* cat, char* w16, char* w6, int64_t* w16_bytes, int64_t* w6_bytes) {
-    if (w16_bytes) *w16_bytes = (int64_t)CTX16_BYTES;
-    if (w6_bytes) *w6_bytes = (int64_t)CTX6_BYTES;
-    if (!cat || !w16 || !w6) return LG_OK;
-    std::vector<char> a, b;
-    pack_ctx6(std::vector<double>(cat, cat + (size_t)512 * 512), a, b);
-    std::memcpy(w16, a.data(), a.size()); std::memcpy(w6, b.data(), b.size());
-    return LG_OK;
-}
-#endif
 
 }  // extern "C"

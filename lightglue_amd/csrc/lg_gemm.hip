@@ -8,9 +8,9 @@
 // next stage's global loads in flight while the current stage is multiplied.
 // LDS rows are 128 B, 16-byte slots XOR-swizzled (lg_common.h lds_off) => conflict-free b128 reads.
 //
-// PREC_BF16X3 ("split bf16"): x = hi + lo, three MFMAs per product (hi*hi + hi*lo + lo*hi), fp32
-// accumulate — the gfx950 stand-in for the xf32 path that CDNA4 dropped; ~2^-16 relative operand
-// error, which is what index parity with the fp32 reference needs (DESIGN.md §numerics).
+// PREC_F16X3 ("split f16"): x = hi + lo (both f16), three MFMAs per product (hi*hi + hi*lo + lo*hi), fp32
+// accumulate — the gfx950 stand-in for the xf32 path that CDNA4 dropped; ~2^-22 relative operand
+// error, which is what index parity with the fp32 reference needs (DESIGN.md §1).
 #include "lg_kernels.h"
 
 namespace lg {
@@ -22,7 +22,6 @@ template <int PREC> struct PT;
 template <> struct PT<PREC_F32> { typedef TagF32 Tag; static constexpr int KE = 32, NPART = 1; };
 template <> struct PT<PREC_BF16> { typedef TagBF16 Tag; static constexpr int KE = 64, NPART = 1; };
 template <> struct PT<PREC_F16> { typedef TagF16 Tag; static constexpr int KE = 64, NPART = 1; };
-template <> struct PT<PREC_BF16X3> { typedef TagBF16 Tag; static constexpr int KE = 64, NPART = 2; };
 template <> struct PT<PREC_F16X3> { typedef TagF16 Tag; static constexpr int KE = 64, NPART = 2; };
 
 // Register image of one fp32-sourced operand tile slice owned by a thread: 4 chunks.
@@ -152,12 +151,7 @@ __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[4][4], const float* A
     }
 }
 
-template <class T> __device__ __forceinline__ T cvt_out(float x);
-template <> __device__ __forceinline__ float cvt_out<float>(float x) { return x; }
-template <> __device__ __forceinline__ bf16_t cvt_out<bf16_t>(float x) { return (bf16_t)x; }
-template <> __device__ __forceinline__ f16_t cvt_out<f16_t>(float x) { return (f16_t)x; }
-
-template <int PREC, int EPI, class TA>
+template <int PREC, int EPI>
 __global__ __launch_bounds__(GTHREADS) void gemm_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware tile order (guide T1): workgroup id b runs on XCD b % 8, so give every XCD a contiguous
@@ -187,7 +181,7 @@ __global__ __launch_bounds__(GTHREADS) void gemm_kernel(GemmArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 15, g = lane >> 4;
-    if constexpr (EPI == EPI_STORE || EPI == EPI_RESID) {
+    {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int col = n0 + wn * 64 + nt * 16 + lr;
@@ -201,53 +195,6 @@ __global__ __launch_bounds__(GTHREADS) void gemm_kernel(GemmArgs a) {
                     const float v = acc[mt][nt][r] + bv;
                     if constexpr (EPI == EPI_STORE) *p = v * a.out_scale; else *p += v;
                 }
-        }
-    } else {  // EPI_QKV
-        // column n = group*256 + head*64 + d ; this wave's 64 columns are exactly one (group, head)
-        const int cbase = n0 + wn * 64;
-        const int group = cbase >> 8, head = (cbase >> 6) & 3;
-        const bool is_v = group >= a.n_qk_groups;
-        if (!is_v) {
-            TA* dst = static_cast<TA*>(group == 0 ? a.q : a.k);
-            const bool rope = a.cosb != nullptr;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const long long row = t.grow0 + wm * 64 + mt * 16 + g * 4 + r;
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
-                        const int d = nt * 16 + lr;
-                        float v = acc[mt][nt][r] + bias[cbase + d];
-                        if (rope) {
-                            // ref :58-65: pairs are adjacent columns (2j, 2j+1) = adjacent lanes
-                            const float other = __shfl_xor(v, 1, 64);
-                            const float c = a.cosb[row * 32 + (d >> 1)], s = a.sinb[row * 32 + (d >> 1)];
-                            v = (d & 1) ? (v * c + other * s) : (v * c - other * s);
-                        }
-                        dst[((long long)head * a.R + row) * 64 + d] = cvt_out<TA>(v);
-                    }
-                }
-        } else {
-            TA* dst = static_cast<TA*>(a.vt);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int d = nt * 16 + lr;
-                const float bv = bias[cbase + d];
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const long long row = t.grow0 + wm * 64 + mt * 16 + g * 4;  // 4 consecutive rows
-                    TA* p = dst + ((long long)head * 64 + d) * a.R + row;
-                    if constexpr (sizeof(TA) == 4) {
-                        *reinterpret_cast<f32x4*>(p) = f32x4{acc[mt][nt][0] + bv, acc[mt][nt][1] + bv, acc[mt][nt][2] + bv, acc[mt][nt][3] + bv};
-                    } else {
-                        typedef TA ta4 __attribute__((ext_vector_type(4)));
-                        ta4 o = {cvt_out<TA>(acc[mt][nt][0] + bv), cvt_out<TA>(acc[mt][nt][1] + bv),
-                                 cvt_out<TA>(acc[mt][nt][2] + bv), cvt_out<TA>(acc[mt][nt][3] + bv)};
-                        *reinterpret_cast<ta4*>(p) = o;
-                    }
-                }
-            }
         }
     }
 }
@@ -276,11 +223,11 @@ __global__ __launch_bounds__(GTHREADS) void sim_kernel(SimArgs a) {
 
 template <int PREC> static constexpr int smem_bytes() { return 2 * PT<PREC>::NPART * TILE_BYTES; }
 
-template <int PREC, int EPI, class TA>
+template <int PREC, int EPI>
 static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
     const int R = a.rs.B * (a.rs.cap0 + a.rs.cap1);
     dim3 grid((R / GBM) * (a.Nout / GBN));
-    auto kern = gemm_kernel<PREC, EPI, TA>;
+    auto kern = gemm_kernel<PREC, EPI>;
     constexpr int smem = smem_bytes<PREC>();
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -291,28 +238,21 @@ static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
 }
 
 template <int PREC>
-static hipError_t launch_prec(int epi, int attn_prec, const GemmArgs& a, hipStream_t s) {
+static hipError_t launch_prec(int epi, const GemmArgs& a, hipStream_t s) {
     switch (epi) {
-        case EPI_STORE: return launch_one<PREC, EPI_STORE, float>(a, s);
-        case EPI_RESID: return launch_one<PREC, EPI_RESID, float>(a, s);
-        case EPI_QKV:
-            switch (attn_prec) {
-                case PREC_F32: return launch_one<PREC, EPI_QKV, float>(a, s);
-                case PREC_BF16: return launch_one<PREC, EPI_QKV, bf16_t>(a, s);
-                case PREC_F16: return launch_one<PREC, EPI_QKV, f16_t>(a, s);
-            }
+        case EPI_STORE: return launch_one<PREC, EPI_STORE>(a, s);
+        case EPI_RESID: return launch_one<PREC, EPI_RESID>(a, s);
     }
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_gemm(int prec, int epi, int attn_prec, const GemmArgs& a, hipStream_t s) {
+hipError_t launch_gemm(int prec, int epi, const GemmArgs& a, hipStream_t s) {
     if (a.Nout % GBN || a.K % 64 || a.K1 % 64 || a.rs.cap0 % GBM || a.rs.cap1 % GBM) return hipErrorInvalidValue;
     switch (prec) {
-        case PREC_F32: return launch_prec<PREC_F32>(epi, attn_prec, a, s);
-        case PREC_BF16: return launch_prec<PREC_BF16>(epi, attn_prec, a, s);
-        case PREC_F16: return launch_prec<PREC_F16>(epi, attn_prec, a, s);
-        case PREC_BF16X3: return launch_prec<PREC_BF16X3>(epi, attn_prec, a, s);
-        case PREC_F16X3: return launch_prec<PREC_F16X3>(epi, attn_prec, a, s);
+        case PREC_F32: return launch_prec<PREC_F32>(epi, a, s);
+        case PREC_BF16: return launch_prec<PREC_BF16>(epi, a, s);
+        case PREC_F16: return launch_prec<PREC_F16>(epi, a, s);
+        case PREC_F16X3: return launch_prec<PREC_F16X3>(epi, a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -334,7 +274,6 @@ hipError_t launch_sim(int prec, const SimArgs& a, hipStream_t s) {
         case PREC_F32: return launch_sim_prec<PREC_F32>(a, s);
         case PREC_BF16: return launch_sim_prec<PREC_BF16>(a, s);
         case PREC_F16: return launch_sim_prec<PREC_F16>(a, s);
-        case PREC_BF16X3: return launch_sim_prec<PREC_BF16X3>(a, s);
         case PREC_F16X3: return launch_sim_prec<PREC_F16X3>(a, s);
     }
     return hipErrorInvalidValue;

@@ -8,8 +8,8 @@ namespace lg {
 // ---------------------------------------------------------------- GEMM  (lg_gemm.hip)
 // Y[row, n] = sum_k A[row, k] * W[n, k] (+ bias[n]);  A is fp32 in HBM and converted to the operand
 // precision while it is staged into LDS; W is pre-packed in the operand precision ([Nout][K], K
-// contiguous; hi and lo halves for PREC_BF16X3).
-enum : int { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2 };
+// contiguous; hi and lo halves for PREC_F16X3).
+enum : int { EPI_STORE = 0, EPI_RESID = 1 };
 
 struct GemmArgs {
     RowSpace rs;
@@ -24,14 +24,9 @@ struct GemmArgs {
     const int* layer_of_pair; long long w_layer_stride; long long b_layer_stride;
     // EPI_STORE / EPI_RESID
     float* out; int ldo; float out_scale;
-    // EPI_QKV: columns are [group][head][64]; groups < n_rope_groups... see lg_gemm.hip
-    void* q; void* k; void* vt;   // q,k: [H][R][64]   vt: [H][64][R]   (element = attention type)
-    const float* cosb; const float* sinb;  // [R][32] rotary tables (nullptr = no rotary)
-    int n_qk_groups;              // 2 for self (q,k,v), 1 for cross (qk,v)
     int R;                        // total rows (= B*(cap0+cap1))
 };
-// attn_prec selects the element type written by EPI_QKV (PREC_F32 / PREC_BF16 / PREC_F16)
-hipError_t launch_gemm(int prec, int epi, int attn_prec, const GemmArgs& a, hipStream_t s);
+hipError_t launch_gemm(int prec, int epi, const GemmArgs& a, hipStream_t s);
 
 // sim[pair][a][b] = sum_k X[row(2*pair, a), k] * X[row(2*pair+1, b), k]   (both operands fp32 rows)
 struct SimArgs {
@@ -48,7 +43,8 @@ struct ProjArgs {
     RowSpace rs;
     const float* X;
     const void* W; const float* bias; int Nout;       // 768 (self) or 512 (cross)
-    void* q; void* k; void* vt;                      // q,k: [H][R][64]   vt: [H][64][R]
+    void* q; void* k; void* vt;                      // q,k: [H][R][64]   vt: [H][64][R]; q and k pre-scaled by QK_PRESCALE (lg_proj_body.h)
+    long long plane;                                 // split attention (PREC_F16X3): element distance from the hi to the lo plane of q / k / vt
     const float* cosb; const float* sinb;            // rotary tables [R][32] or nullptr
     int n_qk_groups; int R;
     long long* dbg;                                  // profiling tap: [blocks][8 waves][8] shader-clock stamps, or nullptr
@@ -70,29 +66,18 @@ struct TailArgs {
     // optional: the NEXT block's q/k/v projection, run on the x tile this kernel has just produced (next.W == nullptr:
     // none).  next.X is unused; supported for 16-bit operand / attention precisions (launch_tail_supports_next).
     ProjArgs next;
-#ifdef LG_EXPERIMENTS
-    // ctx-half experiment (lg_tail.hip LG_TAIL_CTX_FP6, precision f16x3): the ctx half of Wcat re-packed as f16 fragments in the
-    // block-consecutive k order ([n-tile 32][c 2][q 4][lane 64][16 B]) and fp6 lo records ([n-tile 32][c 2][lane 64][32 B])
-    const void* Wc16; const void* Wc6;
-#endif
 };
 bool launch_tail_supports_next(int prec, int attn_prec);
-hipError_t launch_tail_rows128(const TailArgs& a, hipStream_t s);   // experiment builds: 128 rows per workgroup, PREC_BF16X3 + f16 attention only (lg_tail128.hip)
 hipError_t launch_tail(int prec, int attn_prec, const TailArgs& a, hipStream_t s);    // 8 waves, one workgroup per CU (lg_tail.hip)
-// experiment builds only (-DLG_EXPERIMENTS, lg_tail4.hip): streaming decompositions measured against the default, all slower
-hipError_t launch_tail4(int prec, const TailArgs& a, hipStream_t s);   // 4 waves x 64 rows, two workgroups per CU (lg_tail4.hip)
-hipError_t launch_tail128(int prec, const TailArgs& a, hipStream_t s); // 8 waves x 128 rows: half the weight stream per row (lg_tail4.hip)
-hipError_t launch_tail32(int prec, const TailArgs& a, hipStream_t s);  // 4 waves x 32 rows: twice the workgroups, for under-filled grids (lg_tail4.hip)
-
 // ---------------------------------------------------------------- attention (lg_attention.hip)
 struct AttnArgs {
     RowSpace rs;
-    const void* q; const void* k; const void* vt;  // see GemmArgs
+    const void* q; const void* k; const void* vt;  // see ProjArgs: q, k arrive pre-scaled, scores are base-2 logits
+    long long plane;  // PREC_F16X3: element distance from the hi to the lo plane of q / k / vt
     float* ctx;       // [R][256] fp32, column = head*64 + d
     int R; int cross; // cross: segment s attends to segment s^1 (q and k both read from `q`)
-    float scale_log2e;
     long long* dbg;   // profiling builds (-DLG_ATTN_TIMING) only: [blocks][4 waves][8] phase clock sums
-    int rows_per_wave;   // 32 or 64 query rows per wave (see launch_attention)
+    int rows_per_wave;   // 16, 32 or 64 query rows per wave (see launch_attention)
     int dma;             // 16-bit, 32 rows per wave: the LDS-DMA kernel (attn_dma_kernel)
 };
 hipError_t launch_attention(int attn_prec, const AttnArgs& a, hipStream_t s);

@@ -5,7 +5,7 @@
 //
 // Same structure as the fused tail (lg_tail.hip): workgroup = 64 keypoint rows x ALL output columns, 8 waves
 // split the columns; the 64 x 256 activation tile is read from HBM exactly once, converted to the operand
-// precision and kept in LDS (64 KB as split bf16); weight fragments come pre-packed in MFMA order straight
+// precision and kept in LDS (64 KB as split f16); weight fragments come pre-packed in MFMA order straight
 // from L2 (one coalesced 1 KB wave load each).  Wave w owns the n-tiles {w + 8j}: the columns are produced in
 // two passes of NTP n-tiles per wave (keeps accumulators + weight ring under the register budget); the outputs
 // leave straight from the accumulators (lg_proj_body.h: transposed MFMA form for q/k, plain form for v^T).
@@ -43,9 +43,9 @@ __global__ __launch_bounds__(PTHREADS) void proj_kernel(ProjArgs a) {
             char* tile = smA + st * TILE;
             if constexpr (PREC == PREC_F32) {
                 *reinterpret_cast<f32x4*>(tile + off) = hreg[st][0];
-            } else if constexpr (PREC == PREC_BF16X3) {
+            } else if constexpr (PJ<PREC>::APART == 2) {
                 u32x4 hi, lo;
-                split8_bf16(hreg[st][0], hreg[st][1], hi, lo);
+                split8<Tag>(hreg[st][0], hreg[st][1], hi, lo);
                 *reinterpret_cast<u32x4*>(tile + off) = hi;
                 *reinterpret_cast<u32x4*>(tile + A_PLANE + off) = lo;
             } else {   // single plane (PREC_QKV_F16W2: one f16 plane)
@@ -70,21 +70,14 @@ template <int PREC, class TA> static hipError_t launch_proj_n(const ProjArgs& a,
     if (a.Nout == 512 && a.n_qk_groups == 1) return launch_proj_t<PREC, TA, 2, 2>(a, s);
     return hipErrorInvalidValue;
 }
-template <int PREC> static hipError_t launch_proj_p(int attn_prec, const ProjArgs& a, hipStream_t s) {
-    switch (attn_prec) {
-        case PREC_F32: return launch_proj_n<PREC, float>(a, s);
-        case PREC_BF16: return launch_proj_n<PREC, bf16_t>(a, s);
-        case PREC_F16: return launch_proj_n<PREC, f16_t>(a, s);
-    }
-    return hipErrorInvalidValue;
-}
+// (linear precision, attention precision) pairs the engine runs: every single-plane precision with its own element type,
+// f16x3 with split q / k / v (default) or with one f16 plane (attention_precision fp16, lg_proj_body.h PREC_QKV_F16W2)
 hipError_t launch_proj(int prec, int attn_prec, const ProjArgs& a, hipStream_t s) {
-    switch (prec) {
-        case PREC_F32: return launch_proj_p<PREC_F32>(attn_prec, a, s);
-        case PREC_BF16: return launch_proj_p<PREC_BF16>(attn_prec, a, s);
-        case PREC_F16: return launch_proj_p<PREC_F16>(attn_prec, a, s);
-        case PREC_BF16X3: case PREC_F16X3: return launch_proj_p<PREC_QKV_F16W2>(attn_prec, a, s);   // f16 activations x split-f16 weights (lg_proj_body.h)
-    }
+    if (prec == PREC_F32 && attn_prec == PREC_F32) return launch_proj_n<PREC_F32, float>(a, s);
+    if (prec == PREC_BF16 && attn_prec == PREC_BF16) return launch_proj_n<PREC_BF16, bf16_t>(a, s);
+    if (prec == PREC_F16 && attn_prec == PREC_F16) return launch_proj_n<PREC_F16, f16_t>(a, s);
+    if (prec == PREC_F16X3 && attn_prec == PREC_F16X3) return a.plane > 0 ? launch_proj_n<PREC_F16X3, f16_t>(a, s) : hipErrorInvalidValue;
+    if (prec == PREC_F16X3 && attn_prec == PREC_F16) return launch_proj_n<PREC_QKV_F16W2, f16_t>(a, s);
     return hipErrorInvalidValue;
 }
 

@@ -10,31 +10,25 @@
 namespace lg {
 
 constexpr int PBM = 64, PTHREADS = 512;
-#ifndef LG_PROJ_PINGPONG
-#define LG_PROJ_PINGPONG 0       // scheduling experiment (same arithmetic): waves 4..7 run both MFMA loops of the projection before both epilogues
-#endif
-#ifndef LG_PROJ_ABLATE_W
-#define LG_PROJ_ABLATE_W 0       // timing ablation (wrong results): constant weight fragments in the projection's MFMA loop
-#endif
-#ifndef LG_PROJ_EPI_PREFETCH
-#define LG_PROJ_EPI_PREFETCH 0   // scheduling experiment (same arithmetic): 1 = issue the epilogue's bias / rotary loads before the MFMA loop (+60 live VGPRs, no exposed L2 round trip at the head of the two epilogues)
-#endif
-#ifndef LG_ATTN_FOLD
-#define LG_ATTN_FOLD 0   // experiment, see lg_attention.hip: q and k leave the projection pre-multiplied by the square root of the score scale
-#endif
+// q and k leave every projection pre-multiplied by the SQUARE ROOT of the attention's score scale, sqrt(log2(e) / sqrt(64)) — the
+// reference's own CPU path splits its scale over both operands the same way (lightglue.py:215) — so that the attention kernels
+// exponentiate the MFMA result directly (exp2, no per-score multiply; round 3 A/B: +1.6 % whole step, max |dscore| 4.2e-4 -> 2.8e-4).
+constexpr float QK_PRESCALE = 0.42466090014400953f;
 
-// Operand scheme of the projection.  NPART = weight planes, APART = activation planes.
-// PREC_QKV_F16W2 is what the default precision ("bf16x3") uses for the q/k/v projections: the activation tile as ONE f16
-// plane, the weights as split f16 (hi + lo), i.e. TWO MFMAs per product instead of the three of split-bf16.  q/k/v leave
-// this kernel rounded to f16 for the attention anyway, so rounding x to f16 first costs nothing measurable (operand-rounding study,
-// max |dscore| 2.3-3.0e-4 vs 2.2-2.5e-4 for split-bf16; a single f16 product would give 1.0-1.6e-3).
+// Operand scheme of the projection.  NPART = weight planes, APART = activation planes, OPART = planes of q / k / v written.
+//   PREC_F16X3      (default): split-f16 activations x split-f16 weights, THREE MFMAs per product, and q / k / v leave as split f16
+//                   (hi + lo planes) for the split attention kernel — what holds the 1e-3 score bar when attention logits are sharp
+//                   (recipe-D fixtures: one f16 plane anywhere on the q.k path costs 1e-2 in the scores).
+//   PREC_QKV_F16W2  (precision f16x3 with attention_precision fp16, the fast opt-in): the activation tile as ONE f16 plane, the
+//                   weights as split f16, TWO MFMAs per product; q / k / v rounded to one f16 plane (what the reference's own GPU
+//                   path feeds its fp16 SDPA, lightglue.py:119).  Holds the bar only while attention is diffuse (recipes A-C).
 constexpr int PREC_QKV_F16W2 = 100;
 template <int PREC> struct PJ;
-template <> struct PJ<PREC_F32> { typedef TagF32 Tag; static constexpr int NPART = 1, APART = 1; };
-template <> struct PJ<PREC_BF16> { typedef TagBF16 Tag; static constexpr int NPART = 1, APART = 1; };
-template <> struct PJ<PREC_F16> { typedef TagF16 Tag; static constexpr int NPART = 1, APART = 1; };
-template <> struct PJ<PREC_BF16X3> { typedef TagBF16 Tag; static constexpr int NPART = 2, APART = 2; };
-template <> struct PJ<PREC_QKV_F16W2> { typedef TagF16 Tag; static constexpr int NPART = 2, APART = 1; };
+template <> struct PJ<PREC_F32> { typedef TagF32 Tag; static constexpr int NPART = 1, APART = 1, OPART = 1; };
+template <> struct PJ<PREC_BF16> { typedef TagBF16 Tag; static constexpr int NPART = 1, APART = 1, OPART = 1; };
+template <> struct PJ<PREC_F16> { typedef TagF16 Tag; static constexpr int NPART = 1, APART = 1, OPART = 1; };
+template <> struct PJ<PREC_F16X3> { typedef TagF16 Tag; static constexpr int NPART = 2, APART = 2, OPART = 2; };
+template <> struct PJ<PREC_QKV_F16W2> { typedef TagF16 Tag; static constexpr int NPART = 2, APART = 1, OPART = 1; };
 
 // acc += product of one weight fragment set (NPART planes) and one activation fragment set (APART planes).  TRANSPOSED: the
 // weights are the A operand.  split x split: hi*lo + lo*hi + hi*hi; split weights x single activation: lo*x + hi*x.
@@ -71,15 +65,9 @@ template <int PREC> struct PJL {   // LDS geometry of the activation tile
 //     [head][64][R] layout (4 consecutive rows of one channel).
 // Nothing is staged through LDS and no barrier follows the MFMA loop (the staged version spent 40 % of the kernel in its two
 // epilogues: LDS write, barrier, LDS read, store, barrier).
-#if LG_PROJ_PINGPONG   // experiment: PART 0 = the whole pass (as the product), 1 = its MFMA loop only, 2 = its epilogue only; accumulators owned by the caller
-template <int PREC, class TA, int NTP, int NPASS, int PASS, int A_PLANE, int MT, int PART>
-__device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, const char* smA, u32x4 (&bf)[PJ<PREC>::NPART == 2 ? 2 : 4][NTP][PJ<PREC>::NPART],
-                                          int stamp_base, f32x4 (&acc)[MT][NTP]) {
-#else
 template <int PREC, class TA, int NTP, int NPASS, int PASS, int A_PLANE, int MT>
 __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, const char* smA, u32x4 (&bf)[PJ<PREC>::NPART == 2 ? 2 : 4][NTP][PJ<PREC>::NPART],
                                           int stamp_base) {
-#endif
     typedef typename PJ<PREC>::Tag Tag;
     constexpr int NPART = PJ<PREC>::NPART, APART = PJ<PREC>::APART;
     constexpr int STAGES = PJL<PREC>::STAGES, NKC = 2 * STAGES, TILE = MT * 16 * 128;   // one plane of one K stage: MT*16 rows x 128 B
@@ -91,9 +79,6 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
         if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8 + stamp_base + slot] = clock64();
     };
     auto wfrag = [&](int p, int nt, int kc) -> u32x4 {
-#if LG_PROJ_ABLATE_W   // TIMING ABLATION ONLY (wrong results): no weight loads at all — is the loop bound by the L2 weight stream?
-        return u32x4{0x3c003c00u + (unsigned)lane, 0x3c003c00u + (unsigned)(nt + kc), 0x3c003c00u + (unsigned)p, 0x3c003c00u};
-#endif
         const char* ptr = static_cast<const char*>(a.W) + (p ? (long long)a.Nout * 256 * (long long)sizeof(typename Tag::elem) : 0);
         return *reinterpret_cast<const u32x4*>(ptr + ((long long)(nt * NKC + kc) * 64 + lane) * 16);
     };
@@ -103,39 +88,11 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
 #pragma unroll
             for (int p = 0; p < NPART; ++p) dst[j][p] = wfrag(p, w + 8 * (pass * NTP + j), kc);
     };
-#if LG_PROJ_PINGPONG
-    if constexpr (PART != 2) {
-#else
     f32x4 acc[MT][NTP];
-#endif
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NTP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if LG_PROJ_EPI_PREFETCH   // experiment: the epilogue's operands (bias, rotary tables) are fetched BEFORE the MFMA loop instead of after it
-    typedef TA ta4 __attribute__((ext_vector_type(4)));
-    f32x4 b4[NTP]; float bv[NTP];
-    f32x2 c2[NTP][MT], s2[NTP][MT];
-#pragma unroll
-    for (int j = 0; j < NTP; ++j) {
-        constexpr int dummy = 0; (void)dummy;
-        const int jj = PASS * NTP + j;
-        const int col0 = (w + 8 * jj) * 16, d0 = col0 & 63;
-        if ((jj >> 1) < N_QK) {
-            b4[j] = *reinterpret_cast<const f32x4*>(a.bias + col0 + 4 * g);
-            if constexpr (NTP == 3) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const long long row = t.grow0 + mt * 16 + lr;
-                    c2[j][mt] = *reinterpret_cast<const f32x2*>(a.cosb + row * 32 + (d0 >> 1) + 2 * g);
-                    s2[j][mt] = *reinterpret_cast<const f32x2*>(a.sinb + row * 32 + (d0 >> 1) + 2 * g);
-                }
-            }
-        } else {
-            bv[j] = a.bias[col0 + lr];
-        }
-    }
-#endif
 #pragma unroll 1
     for (int c0 = 0; c0 < NKC; c0 += NBUF) {
 #pragma unroll
@@ -169,15 +126,12 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
         }
     }
     stamp(2 + 2 * PASS);
-#if LG_PROJ_PINGPONG
-    }
-    if constexpr (PART == 1) return;
-#endif
     // ---- epilogue of the pass, straight from the accumulators.  All loads (bias, rotary tables) are issued BEFORE the first
     // store: the compiler cannot prove that q/k/v do not alias the tables, so a load placed after a store stays there and
     // every (tile, 16-row tile) iteration would expose one full L2 round trip (measured: 14k cycles for 12 iterations).
-#if !LG_PROJ_EPI_PREFETCH
     typedef TA ta4 __attribute__((ext_vector_type(4)));
+    constexpr int OPART = PJ<PREC>::OPART;
+    static_assert(OPART == 1 || sizeof(TA) == 2, "split q / k / v planes are f16");
     f32x4 b4[NTP]; float bv[NTP];
     f32x2 c2[NTP][MT], s2[NTP][MT];
 #pragma unroll
@@ -199,7 +153,6 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
             bv[j] = a.bias[col0 + lr];
         }
     }
-#endif
 #pragma unroll
     for (int j = 0; j < NTP; ++j) {
         constexpr int dummy = 0; (void)dummy;
@@ -218,17 +171,32 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
                     v[0] = u[0] * c[0] - u[1] * sn[0]; v[1] = u[1] * c[0] + u[0] * sn[0];
                     v[2] = u[2] * c[1] - u[3] * sn[1]; v[3] = u[3] * c[1] + u[2] * sn[1];
                 }
-#if LG_ATTN_FOLD
-                v *= 0.42466090014400953f;                // sqrt(log2(e) / sqrt(64)): the attention's score scale, split over q and k (lg_attention.hip LG_ATTN_FOLD)
-#endif
-                ta4 o = {pj_cvt<TA>(v[0]), pj_cvt<TA>(v[1]), pj_cvt<TA>(v[2]), pj_cvt<TA>(v[3])};
-                *reinterpret_cast<ta4*>(base + ((long long)head * R + row) * 64 + d0 + 4 * g) = o;
+                v *= QK_PRESCALE;
+                TA* dst = base + ((long long)head * R + row) * 64 + d0 + 4 * g;
+                if constexpr (OPART == 2) {               // hi plane + lo plane (f16 of the residual, exact subtraction in fp32)
+                    uint32_t h01, l01, h23, l23;
+                    split2_f16(v[0], v[1], h01, l01); split2_f16(v[2], v[3], h23, l23);
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{h01, h23};
+                    *reinterpret_cast<u32x2*>(dst + a.plane) = u32x2{l01, l23};
+                } else {
+                    ta4 o = {pj_cvt<TA>(v[0]), pj_cvt<TA>(v[1]), pj_cvt<TA>(v[2]), pj_cvt<TA>(v[3])};
+                    *reinterpret_cast<ta4*>(dst) = o;
+                }
             }
         } else {                                          // v: plain tile -> transposed layout [head][64][R]
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                ta4 o = {pj_cvt<TA>(acc[mt][j][0] + bv[j]), pj_cvt<TA>(acc[mt][j][1] + bv[j]), pj_cvt<TA>(acc[mt][j][2] + bv[j]), pj_cvt<TA>(acc[mt][j][3] + bv[j])};
-                *reinterpret_cast<ta4*>(static_cast<TA*>(a.vt) + ((long long)head * 64 + d0 + lr) * R + t.grow0 + mt * 16 + 4 * g) = o;
+                const f32x4 v = acc[mt][j] + bv[j];
+                TA* dst = static_cast<TA*>(a.vt) + ((long long)head * 64 + d0 + lr) * R + t.grow0 + mt * 16 + 4 * g;
+                if constexpr (OPART == 2) {
+                    uint32_t h01, l01, h23, l23;
+                    split2_f16(v[0], v[1], h01, l01); split2_f16(v[2], v[3], h23, l23);
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{h01, h23};
+                    *reinterpret_cast<u32x2*>(dst + a.plane) = u32x2{l01, l23};
+                } else {
+                    ta4 o = {pj_cvt<TA>(v[0]), pj_cvt<TA>(v[1]), pj_cvt<TA>(v[2]), pj_cvt<TA>(v[3])};
+                    *reinterpret_cast<ta4*>(dst) = o;
+                }
             }
         }
     }
@@ -257,24 +225,8 @@ __device__ __forceinline__ void proj_compute(const ProjArgs& a, const TileLoc& t
             }
     __syncthreads();   // the activation tile is complete
     if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8 + stamp_base + 1] = clock64();
-#if LG_PROJ_PINGPONG
-    // The two waves of a SIMD (w, w + 4) run the passes in DIFFERENT shapes: waves 0..3 as the product (MFMA loop, epilogue, MFMA loop,
-    // epilogue), waves 4..7 both MFMA loops first and both epilogues after — so that an epilogue (VALU, loads, stores) of one wave
-    // faces an MFMA loop of the other instead of the other's epilogue.  Same arithmetic per wave: bit-identical outputs.
-    f32x4 acc0[MT][NTP], acc1[MT][NTP];
-    if (w >= 4) {
-        proj_pass<PREC, TA, NTP, NPASS, 0, A_PLANE, MT, 1>(a, t, smA, bf, stamp_base, acc0);
-        proj_pass<PREC, TA, NTP, NPASS, 1, A_PLANE, MT, 1>(a, t, smA, bf, stamp_base, acc1);
-        proj_pass<PREC, TA, NTP, NPASS, 0, A_PLANE, MT, 2>(a, t, smA, bf, stamp_base, acc0);
-        proj_pass<PREC, TA, NTP, NPASS, 1, A_PLANE, MT, 2>(a, t, smA, bf, stamp_base, acc1);
-    } else {
-        proj_pass<PREC, TA, NTP, NPASS, 0, A_PLANE, MT, 0>(a, t, smA, bf, stamp_base, acc0);
-        proj_pass<PREC, TA, NTP, NPASS, 1, A_PLANE, MT, 0>(a, t, smA, bf, stamp_base, acc0);
-    }
-#else
     proj_pass<PREC, TA, NTP, NPASS, 0, A_PLANE, MT>(a, t, smA, bf, stamp_base);
     proj_pass<PREC, TA, NTP, NPASS, 1, A_PLANE, MT>(a, t, smA, bf, stamp_base);
-#endif
 }
 
 }  // namespace lg

@@ -23,7 +23,7 @@
 //   * GELU output, residual and the next projection's activation tile are 8/16-byte accesses of 4 consecutive
 //     elements of one row: no lane-pair transposition, no staging of the output tile through LDS.
 //   phase A  h = [x ; ctx] Wcat^T + bcat.  The whole 64 x 512 activation tile lives in LDS (128 KB as split
-//            bf16): the x half is loaded/converted first, the ctx half is fetched while the x half is being
+//            f16): the x half is loaded/converted first, the ctx half is fetched while the x half is being
 //            multiplied -> two barriers for the whole phase, weight fragments prefetched from L2 on a ring.
 //   LN       per-wave (mean, M2) over its 64 hidden units in registers, ONE exchange through LDS, merged with the
 //            parallel-variance formula (exactly a two-pass variance; one barrier pair instead of two)
@@ -40,23 +40,10 @@ namespace lg {
 
 constexpr int TTHREADS = 512;
 
-// Scheduling experiments (tools/build_variant.sh <name> -DLG_TAIL_STEP_ORDER=1 ...; the product build leaves both at 0 and its
-// machine code is unchanged by them).  Every setting computes the same values in the same order per element.
-#ifndef LG_TAIL_STEP_ORDER
-#define LG_TAIL_STEP_ORDER 0    // 1: waves 0..3 apply the next GELU BEFORE the step's MFMAs; 2: GELU interleaved with the MFMAs in-wave
-#endif
-#ifndef LG_TAIL_CTX_FP6
-#define LG_TAIL_CTX_FP6 0       // 1 (needs -DLG_EXPERIMENTS, precision f16x3, 64-row tiles): the ctx half of phase A as f16 main product + fp6 cross terms
-#endif
-#ifndef LG_TAIL_GELU_SCALAR
-#define LG_TAIL_GELU_SCALAR 0   // 1: the erf polynomial in scalar v_fma_f32 instead of v_pk_fma_f32 (packed f32 overlaps MFMAs of the other wave badly)
-#endif
-
 template <int PREC> struct TT;
 template <> struct TT<PREC_F32> { typedef TagF32 Tag; static constexpr int KE = 32, NPART = 1; };
 template <> struct TT<PREC_BF16> { typedef TagBF16 Tag; static constexpr int KE = 64, NPART = 1; };
 template <> struct TT<PREC_F16> { typedef TagF16 Tag; static constexpr int KE = 64, NPART = 1; };
-template <> struct TT<PREC_BF16X3> { typedef TagBF16 Tag; static constexpr int KE = 64, NPART = 2; };
 template <> struct TT<PREC_F16X3> { typedef TagF16 Tag; static constexpr int KE = 64, NPART = 2; };
 
 // LDS map (bytes):  [0, G_BYTES) g tiles  — aliased during phase A by the two staging buffers
@@ -95,37 +82,9 @@ __device__ __forceinline__ f32x2 gelu_fast2(f32x2 u) {
     const f32x2 sgn = {copysignf(er[0], x[0]), copysignf(er[1], x[1])};
     return half_u + half_u * sgn;
 }
-#if LG_TAIL_GELU_SCALAR
-// the same arithmetic, one value at a time (v_fma_f32 / v_mul_f32: every packed operation above is the IEEE operation on each half)
-__device__ __forceinline__ float gelu_fast1(float u) {
-    const float x = u * 0.70710678118654752440f;
-    const float ax = fabsf(x);
-    const float tt = __builtin_amdgcn_rcpf(__builtin_fmaf(ax, 0.3275911f, 1.0f));
-    float p = __builtin_fmaf(tt, -0.0779742014f, 0.151737503f);
-    p = __builtin_fmaf(p, tt, 0.39572154f);
-    p = __builtin_fmaf(p, tt, -0.574341196f);
-    p = __builtin_fmaf(p, tt, 0.810336914f);
-    p = __builtin_fmaf(p, tt, -0.151473053f);
-    p = __builtin_fmaf(p, tt, 0.270560832f);
-    p = __builtin_fmaf(p, tt, 0.175431661f);
-    p = p * tt;
-    const float e = __builtin_amdgcn_exp2f(ax * ax * -1.44269504088896340736f);
-    const float er = __builtin_fmaf(-p, e, 1.0f);
-    const float half_u = u * 0.5f;
-    return __builtin_fmaf(half_u, copysignf(er, x), half_u);
-}
-__device__ __forceinline__ f32x2 gelu_pair(f32x2 u) { return f32x2{gelu_fast1(u[0]), gelu_fast1(u[1])}; }
-#else
 __device__ __forceinline__ f32x2 gelu_pair(f32x2 u) { return gelu_fast2(u); }
-#endif
 
-#if LG_TAIL_CTX_FP6
-#define LG_TAIL_CTX6_SECTION 1   // namespace-scope helpers of the ctx-half experiment
-#include "lg_tail_ctx6.h"
-#undef LG_TAIL_CTX6_SECTION
-#endif
-
-// acc (C^T tile) += w x^T for one k-chunk; split-bf16: (w_hi x_lo) + (w_lo x_hi) + (w_hi x_hi)
+// acc (C^T tile) += w x^T for one k-chunk; split-f16: (w_hi x_lo) + (w_lo x_hi) + (w_hi x_hi)
 template <int PREC>
 __device__ __forceinline__ void tail_mma(f32x4& acc, const u32x4* wf, const u32x4* xf) {
     typedef typename TT<PREC>::Tag Tag;
@@ -143,7 +102,10 @@ __device__ __forceinline__ void tail_mma(f32x4& acc, const u32x4* wf, const u32x
 // MT = 16-row tiles per workgroup: 4 (64 rows, the throughput shape) or 2 / 1 for under-filled grids (small batches): the
 // same per-row arithmetic in the same order — outputs are bit-identical — on 2x / 4x as many workgroups; each of them streams
 // the full weight set, so these shapes are L2-stream-bound per CU (~46k cycles) instead of matrix-bound.
-template <int PREC, int NEXT, class TA, int MT>
+// ASPLIT (PREC_F16X3 with NEXT != 0 only): the next projection feeds the SPLIT attention — the new x tile goes to LDS as hi + lo
+// f16 planes, the projection runs three MFMAs per product and writes q / k / v as hi + lo planes (lg_proj_body.h PREC_F16X3);
+// otherwise one f16 plane and two MFMAs per product (PREC_QKV_F16W2, attention precision fp16).
+template <int PREC, int NEXT, class TA, int MT, bool ASPLIT>
 __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     constexpr int TBM = 16 * MT;
     typedef typename TT<PREC>::Tag Tag;
@@ -241,14 +203,6 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) tail_mma<PREC>(acc[mt][nt], b[nt], af[mt]);
     };
-#if LG_TAIL_CTX_FP6   // experiment: phase A with the ctx half on f16 + fp6 (lg_tail_ctx6.h); otherwise the code below
-    constexpr bool CTX6 = PREC == PREC_F16X3 && MT == 4;
-    if constexpr (CTX6) {
-#define LG_TAIL_CTX6_SECTION 2
-#include "lg_tail_ctx6.h"
-#undef LG_TAIL_CTX6_SECTION
-    } else {
-#endif
     load_half(0);
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i) load_b_A(bf[i], i);
@@ -282,9 +236,6 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             __syncthreads();
         }
     }
-#if LG_TAIL_CTX_FP6
-    }
-#endif
     stamp(1);
     // ------------------------------------------------------------------ bias + LayerNorm(512)
     // acc[mt][nt][r] = h[row mt*16 + lr][hidden (w + 8 nt)*16 + 4g + r]
@@ -347,14 +298,11 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             const int row = mt * 16 + lr;
             if constexpr (EPC == 8) {
                 char* dst = smem + (2 * j + (w >> 2)) * TILE + lds_off<128>(row, (w & 3) * 2 + (g >> 1)) + (g & 1) * 8;
-                if constexpr (PREC == PREC_BF16X3) {
-                    const float h0 = bf16_round(v01[0]), h1 = bf16_round(v01[1]), h2 = bf16_round(v23[0]), h3 = bf16_round(v23[1]);
-                    *reinterpret_cast<u32x2*>(dst) = u32x2{pack2_bf16(h0, h1), pack2_bf16(h2, h3)};
-                    *reinterpret_cast<u32x2*>(dst + G_PLANE) = u32x2{pack2_bf16(v01[0] - h0, v01[1] - h1), pack2_bf16(v23[0] - h2, v23[1] - h3)};
-                } else if constexpr (PREC == PREC_F16X3) {
-                    const float h0 = (float)(f16_t)v01[0], h1 = (float)(f16_t)v01[1], h2 = (float)(f16_t)v23[0], h3 = (float)(f16_t)v23[1];
-                    *reinterpret_cast<u32x2*>(dst) = u32x2{pack2_f16(h0, h1), pack2_f16(h2, h3)};
-                    *reinterpret_cast<u32x2*>(dst + G_PLANE) = u32x2{pack2_f16(v01[0] - h0, v01[1] - h1), pack2_f16(v23[0] - h2, v23[1] - h3)};
+                if constexpr (PREC == PREC_F16X3) {
+                    uint32_t h01, l01, h23, l23;
+                    split2_f16(v01[0], v01[1], h01, l01); split2_f16(v23[0], v23[1], h23, l23);
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{h01, h23};
+                    *reinterpret_cast<u32x2*>(dst + G_PLANE) = u32x2{l01, l23};
                 } else {
                     *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<Tag>(v01[0], v01[1]), pack2<Tag>(v23[0], v23[1])};
                 }
@@ -404,41 +352,6 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
                 for (int nt = 0; nt < 2; ++nt)
                     xres[mt][nt] = *reinterpret_cast<const f32x4*>(a.X + (long long)(t.grow0 + mt * 16 + lr) * 256 + w * 32 + nt * 16 + 4 * g);
         }
-#if LG_TAIL_STEP_ORDER != 0
-        auto step_mma = [&]() {
-#pragma unroll
-            for (int i = 0; i < CPS; ++i) {
-                const int kc = j * CPS + i;
-                load_b_B(b2f[(kc + 3) & 3], kc + 3 < NKC ? kc + 3 : NKC - 1);
-                chunk_B(kc, b2f[kc & 3]);
-            }
-        };
-#endif
-#if LG_TAIL_STEP_ORDER == 1
-        // experiment: the two waves of a SIMD (w, w + 4) take the step's two halves in OPPOSITE order, so that one's GELU (VALU)
-        // faces the other's MFMAs instead of both queueing for the same pipe; same arithmetic per wave -> bit-identical outputs
-        if (j < 3 && w < 4) {
-            gelu_store(j + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            step_mma();
-        } else {
-            step_mma();
-            if (j < 3) gelu_store(j + 1);
-        }
-        if (j < 3) __syncthreads();
-#elif LG_TAIL_STEP_ORDER == 2
-        // experiment: the next n-tile's GELU interleaved INSIDE the wave with this step's MFMAs (3 VALU per MFMA issue slot)
-        step_mma();
-        if (j < 3) {
-            gelu_store(j + 1);
-#pragma unroll
-            for (int i = 0; i < 96; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x402, 3, 0);   // three VALU / transcendental
-            }
-            __syncthreads();
-        }
-#else
 #pragma unroll
         for (int i = 0; i < CPS; ++i) {
             const int kc = j * CPS + i;
@@ -449,7 +362,6 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             gelu_store(j + 1);
             __syncthreads();
         }
-#endif
     }
     stamp(4);
     // ------------------------------------------------------------------ epilogue: + b2, + x, store; next block's activation tile
@@ -469,7 +381,12 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             if constexpr (NEXT != 0) {
                 static_assert(EPC == 8, "fused next projection: 16-bit operands only");
                 char* dst = smem + (col >> 6) * TILE + lds_off<128>(row, (col & 63) >> 3) + (col & 7) * 2;
-                if constexpr (NPART == 2) {   // split precisions: the projection takes ONE f16 plane (PREC_QKV_F16W2, lg_proj_body.h)
+                if constexpr (NPART == 2 && ASPLIT) {   // hi + lo planes of the new x tile (lo at G_PLANE: K-stages 0..3 of the lo g plane are just as dead)
+                    uint32_t h01, l01, h23, l23;
+                    split2_f16(xn[0], xn[1], h01, l01); split2_f16(xn[2], xn[3], h23, l23);
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{h01, h23};
+                    *reinterpret_cast<u32x2*>(dst + G_PLANE) = u32x2{l01, l23};
+                } else if constexpr (NPART == 2) {      // the projection takes ONE f16 plane (PREC_QKV_F16W2, lg_proj_body.h)
                     *reinterpret_cast<u32x2*>(dst) = u32x2{pack2_f16(xn[0], xn[1]), pack2_f16(xn[2], xn[3])};
                 } else {
                     *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<Tag>(xn[0], xn[1]), pack2<Tag>(xn[2], xn[3])};
@@ -478,49 +395,49 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         }
     }
     stamp(5);
-    if constexpr (NEXT != 0) proj_compute<(prec_is_split(PREC) ? PREC_QKV_F16W2 : PREC), TA, NEXT == 1 ? 3 : 2, 2, G_PLANE, MT>(a.next, t, smem, 8);
+    if constexpr (NEXT != 0) proj_compute<(prec_is_split(PREC) ? (ASPLIT ? PREC_F16X3 : PREC_QKV_F16W2) : PREC), TA, NEXT == 1 ? 3 : 2, 2, G_PLANE, MT>(a.next, t, smem, 8);
     if (a.dbg && lane == 0)   // wall clock at the end + where the workgroup ran (HW_ID, XCC_ID)
         a.dbg[((long long)blockIdx.x * 8 + w) * 8 + 7] = (wall_clock64() & ((1LL << 44) - 1)) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFF00) << 40) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 44);
 }
 
-template <int PREC, int NEXT, class TA, int MT> static hipError_t launch_tail_m(const TailArgs& a, hipStream_t s) {
+template <int PREC, int NEXT, class TA, int MT, bool ASPLIT> static hipError_t launch_tail_m(const TailArgs& a, hipStream_t s) {
     const int R = a.rs.B * (a.rs.cap0 + a.rs.cap1);
-    auto kern = tail_kernel<PREC, NEXT, TA, MT>;
+    auto kern = tail_kernel<PREC, NEXT, TA, MT, ASPLIT>;
     constexpr int smem = TL<PREC, MT>::TOTAL;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(R / (16 * MT)), dim3(TTHREADS), smem, s, a);
     return hipGetLastError();
 }
-template <int PREC, int NEXT, class TA> static hipError_t launch_tail_t(const TailArgs& a, hipStream_t s) {
-    if constexpr (PREC == PREC_F32) return launch_tail_m<PREC, NEXT, TA, 4>(a, s);   // (the exact mode keeps one shape)
+template <int PREC, int NEXT, class TA, bool ASPLIT> static hipError_t launch_tail_t(const TailArgs& a, hipStream_t s) {
+    if constexpr (PREC == PREC_F32) return launch_tail_m<PREC, NEXT, TA, 4, false>(a, s);   // (the exact mode keeps one shape)
     else {
-        if (a.row_tiles == 1 && !a.dbg) return launch_tail_m<PREC, NEXT, TA, 1>(a, s);
-        if (a.row_tiles == 2 && !a.dbg) return launch_tail_m<PREC, NEXT, TA, 2>(a, s);
-        return launch_tail_m<PREC, NEXT, TA, 4>(a, s);
+        if (a.row_tiles == 1 && !a.dbg) return launch_tail_m<PREC, NEXT, TA, 1, ASPLIT>(a, s);
+        if (a.row_tiles == 2 && !a.dbg) return launch_tail_m<PREC, NEXT, TA, 2, ASPLIT>(a, s);
+        return launch_tail_m<PREC, NEXT, TA, 4, ASPLIT>(a, s);
     }
 }
-template <int PREC, class TA> static hipError_t launch_tail_next(const TailArgs& a, hipStream_t s) {
-    if (!a.next.W) return launch_tail_t<PREC, 0, TA>(a, s);
-    if (a.next.Nout == 768 && a.next.cosb) return launch_tail_t<PREC, 1, TA>(a, s);
-    if (a.next.Nout == 512 && !a.next.cosb) return launch_tail_t<PREC, 2, TA>(a, s);
+template <int PREC, class TA, bool ASPLIT> static hipError_t launch_tail_next(const TailArgs& a, hipStream_t s) {
+    if (!a.next.W) return launch_tail_t<PREC, 0, TA, false>(a, s);
+    if (ASPLIT && a.next.plane <= 0) return hipErrorInvalidValue;
+    if (a.next.Nout == 768 && a.next.cosb) return launch_tail_t<PREC, 1, TA, ASPLIT>(a, s);
+    if (a.next.Nout == 512 && !a.next.cosb) return launch_tail_t<PREC, 2, TA, ASPLIT>(a, s);
     return hipErrorInvalidValue;
 }
 
-// the fused next projection exists for the 16-bit operand / attention combinations the engine runs by default
+// the fused next projection exists for the 16-bit operand / attention combinations the engine runs
 bool launch_tail_supports_next(int prec, int attn_prec) {
-    return (prec_is_split(prec) && attn_prec == PREC_F16) || (prec == PREC_BF16 && attn_prec == PREC_BF16) ||
+    return (prec == PREC_F16X3 && (attn_prec == PREC_F16X3 || attn_prec == PREC_F16)) || (prec == PREC_BF16 && attn_prec == PREC_BF16) ||
            (prec == PREC_F16 && attn_prec == PREC_F16);
 }
 
 hipError_t launch_tail(int prec, int attn_prec, const TailArgs& a, hipStream_t s) {
     if (a.next.W && !launch_tail_supports_next(prec, attn_prec)) return hipErrorInvalidValue;
     switch (prec) {
-        case PREC_F32: return launch_tail_t<PREC_F32, 0, float>(a, s);
-        case PREC_BF16: return launch_tail_next<PREC_BF16, bf16_t>(a, s);
-        case PREC_F16: return launch_tail_next<PREC_F16, f16_t>(a, s);
-        case PREC_BF16X3: return launch_tail_next<PREC_BF16X3, f16_t>(a, s);
-        case PREC_F16X3: return launch_tail_next<PREC_F16X3, f16_t>(a, s);
+        case PREC_F32: return launch_tail_t<PREC_F32, 0, float, false>(a, s);
+        case PREC_BF16: return launch_tail_next<PREC_BF16, bf16_t, false>(a, s);
+        case PREC_F16: return launch_tail_next<PREC_F16, f16_t, false>(a, s);
+        case PREC_F16X3: return attn_prec == PREC_F16X3 ? launch_tail_next<PREC_F16X3, f16_t, true>(a, s) : launch_tail_next<PREC_F16X3, f16_t, false>(a, s);
     }
     return hipErrorInvalidValue;
 }

@@ -12,8 +12,12 @@ Extensions over the reference (documented in DESIGN.md):
   * batches with adaptive depth/width work for B > 1 (every pair stops / prunes independently;
     the reference only defines this for B = 1); ``stop`` is an ``int`` for B = 1 and an
     int64 tensor [B] for B > 1;
-  * ``precision`` conf key: "bf16x3" (default; split-bf16 linear layers + f16 attention — holds index
-    parity with the fp32 reference), "bf16", "fp16", "fp32";
+  * ``precision`` conf key: "f16x3" (default: every contraction — linear layers, q k^T, P V, similarity — on split-f16
+    operands, 3 MFMAs per product; holds index parity / the 1e-3 score bar with the fp32 reference, also for sharp
+    attention), "fp32" (exact f32 MFMAs, the parity anchor), "bf16" / "fp16" (one MFMA per product: fast, outside the bar);
+  * ``attention_precision`` conf key: None (= ``precision``) or "fp16" together with precision "f16x3": q / k / v as ONE f16
+    plane (what the reference's GPU path feeds its fp16 SDPA, ref :119) — ~25 % faster, within the bar only while attention
+    is diffuse (it fails the trained-statistics fixtures by 20x, tests/test_gpu_parity.py);
   * ``pruning_min_kpts`` conf key overrides the device-keyed class dict (ref :339-344).
 """
 from __future__ import annotations
@@ -89,7 +93,8 @@ class LightGlue(nn.Module):
         "filter_threshold": 0.1,
         "weights": None,
         # ---- lightglue_amd extensions
-        "precision": "bf16x3",
+        "precision": "f16x3",
+        "attention_precision": None,
         "pruning_min_kpts": None,  # None -> pruning_keypoint_thresholds (ref :339-344, :658-662)
     }
 
@@ -119,6 +124,8 @@ class LightGlue(nn.Module):
                 setattr(conf, k, v)
         if conf.precision not in _cabi.LG_PREC:
             raise ValueError(f"precision must be one of {sorted(_cabi.LG_PREC)}")
+        if conf.attention_precision not in (None, conf.precision) and not (conf.precision == "f16x3" and conf.attention_precision == "fp16"):
+            raise ValueError("attention_precision must be None (= precision), or 'fp16' together with precision 'f16x3'")
         if conf.descriptor_dim != 256 or conf.num_heads != 4:
             raise ValueError("lightglue_amd builds descriptor_dim=256, num_heads=4 (head_dim 64) only")
 
@@ -224,7 +231,7 @@ class LightGlue(nn.Module):
     def _config_sig(self, device: torch.device):
         c = self.conf
         return (device.index if device.index is not None else torch.cuda.current_device(), c.input_dim, c.n_layers, bool(c.add_scale_ori),
-                float(c.depth_confidence), float(c.width_confidence), float(c.filter_threshold), self.pruning_min_kpts(device), c.precision)
+                float(c.depth_confidence), float(c.width_confidence), float(c.filter_threshold), self.pruning_min_kpts(device), c.precision, c.attention_precision)
 
     def _get_engine(self, device: torch.device):
         lib = _cabi.load()
@@ -235,7 +242,7 @@ class LightGlue(nn.Module):
         c = self.conf
         cfg = _cabi.LgConfig(c.input_dim, c.descriptor_dim, c.n_layers, c.num_heads, int(bool(c.add_scale_ori)),
                              float(c.depth_confidence), float(c.width_confidence), float(c.filter_threshold),
-                             int(sig[7]), _cabi.LG_PREC[c.precision], -1)
+                             int(sig[7]), _cabi.LG_PREC[c.precision], -1 if c.attention_precision is None else _cabi.LG_PREC[c.attention_precision])
         handle = C.c_void_p()
         with torch.cuda.device(device):
             _cabi.check(lib.lg_engine_create(C.byref(cfg), C.byref(handle)))

@@ -104,10 +104,13 @@ def round_fp16x2(x: np.ndarray) -> np.ndarray:
 
 _ROUNDERS = {None: lambda a: a, "fp32": lambda a: a, "bf16": round_bf16, "fp16": round_fp16, "bf16x2": round_bf16x2, "fp16x2": round_fp16x2}
 
-# operand rounding of the HIP path's default precision ("bf16x3"), for emulation studies: split-bf16 linear layers, f16
-# attention, and the q/k/v projections as f16 activations x split-f16 weights (two MFMAs per product; q/k/v are rounded to f16
-# for the attention anyway)
-DEFAULT_PRECISION_QUANT = {"lin": "bf16x2", "attn": "fp16", "final": "bf16x2", "lin_qkv": ("fp16", "fp16x2")}
+# operand rounding of the HIP path's precisions, for emulation studies (tools/emulated_margins.py, tests):
+#   DEFAULT_PRECISION_QUANT  "f16x3": every contraction — linear layers, q k^T, P V, final projection + similarity — on split-f16
+#                            operands (hi + lo, 22 bits), fp32 accumulation
+#   FAST_ATTENTION_QUANT     "f16x3" with attention_precision "fp16" (the opt-in; the round-2 default's arithmetic on f16 planes): the
+#                            q/k/v projections take ONE f16 plane of x (split-f16 weights), q / k / v / P are one f16 plane each
+DEFAULT_PRECISION_QUANT = {"lin": "fp16x2", "attn": "fp16x2", "final": "fp16x2"}
+FAST_ATTENTION_QUANT = {"lin": "fp16x2", "attn": "fp16", "final": "fp16x2", "lin_qkv": ("fp16", "fp16x2")}
 
 
 class _Ctx:

@@ -11,24 +11,32 @@ def to_torch(data, device="cuda"):
     return {k: {kk: torch.from_numpy(np.ascontiguousarray(vv)).to(device) for kk, vv in v.items()} for k, v in data.items()}
 
 
+QK_PRESCALE = 0.42466090014400953   # lg_proj_body.h: q and k leave the projections times sqrt(log2(e) / sqrt(64))
+
+
 def make_model(sd, precision, **conf):
-    model = LightGlue(features=None, precision=precision, **conf).eval()
+    """precision: "fp32" | "bf16" | "fp16" | "f16x3" (default: split attention) | "f16x3/fp16" (f16x3 linear layers with the
+    single-plane f16 attention, the fast opt-in)."""
+    precision, _, attn = precision.partition("/")
+    model = LightGlue(features=None, precision=precision, attention_precision=attn or None, **conf).eval()
     res = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     assert not res.unexpected_keys and set(res.missing_keys) <= {"confidence_thresholds"}, res
     return model
 
 
-ATTN_DTYPE = {"fp32": "f32", "bf16": "bf16", "fp16": "f16", "bf16x3": "f16", "f16x3": "f16"}
-
-
 def read_attn_buf(model, name):
-    kind = ATTN_DTYPE[model.conf.precision]
-    if kind == "f32":
-        return model.debug_read(name, np.float32)
-    if kind == "f16":
-        return model.debug_read(name, np.float16).astype(np.float32)
-    u = model.debug_read(name, np.uint16).astype(np.uint32) << 16
-    return u.view(np.float32)
+    """q / k / v^T as fp32 in the oracle's units: the split attention's hi + lo planes are summed, q and k are un-scaled."""
+    kind = model.conf.attention_precision or model.conf.precision
+    if kind == "fp32":
+        buf = model.debug_read(name, np.float32)
+    elif kind == "fp16":
+        buf = model.debug_read(name, np.float16).astype(np.float32)
+    elif kind == "f16x3":
+        planes = model.debug_read(name, np.float16).astype(np.float32)
+        buf = planes[: planes.size // 2] + planes[planes.size // 2:]
+    else:
+        buf = (model.debug_read(name, np.uint16).astype(np.uint32) << 16).view(np.float32)
+    return buf / np.float32(QK_PRESCALE) if name in ("Q", "K") else buf
 
 
 class Rows:
@@ -67,7 +75,6 @@ def stage_errors(sd, data, precision, conf_kw, layer=0, fused=False):
         traces.append(tr)
     model = make_model(sd, precision, **conf_kw)
     model.set_option("fused_tail", int(fused))   # unfused: every intermediate buffer of the chain exists
-    model.set_option("fused_proj", int(fused))   # unfused: the generic GEMM with the QKV epilogue
     tdata = to_torch(data)
     res = {}
     L = layer

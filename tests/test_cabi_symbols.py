@@ -50,26 +50,35 @@ def test_argument_validation_without_gpu():
     lib = _cabi.load()
     assert lib.lg_version().decode().startswith("lightglue_amd")
     h = ctypes.c_void_p()
-    bad = _cabi.LgConfig(256, 128, 9, 4, 0, 0.95, 0.99, 0.1, -1, 3, -1)  # descriptor_dim != 256
+    bad = _cabi.LgConfig(256, 128, 9, 4, 0, 0.95, 0.99, 0.1, -1, 4, -1)  # descriptor_dim != 256
     assert lib.lg_engine_create(ctypes.byref(bad), ctypes.byref(h)) == _cabi.LG_ERR_INVALID
     assert b"descriptor_dim" in lib.lg_last_error()
     with pytest.raises(AssertionError):
         _cabi.check(_cabi.LG_ERR_INVALID)
-    ok = _cabi.LgConfig(256, 256, 9, 4, 0, 0.95, 0.99, 0.1, -1, 3, -1)
+    ok = _cabi.LgConfig(256, 256, 9, 4, 0, 0.95, 0.99, 0.1, -1, 4, -1)
     assert lib.lg_engine_create(ctypes.byref(ok), ctypes.byref(h)) == _cabi.LG_OK
     # forward before weights -> state error, no GPU touched
     io = _cabi.LgForwardIO()
     io.batch, io.n0, io.n1 = 1, 4, 4
     assert lib.lg_engine_forward(h, ctypes.byref(io), None) == _cabi.LG_ERR_STATE
-    # options: unknown keys and experiment-only switches are refused by the product library, with a message
+    # options: unknown keys (and the switches of removed experiments) are refused, with a message
     assert lib.lg_engine_set_option(h, b"fused_next", 0) == _cabi.LG_OK
     assert lib.lg_engine_set_option(h, b"no_such_option", 1) == _cabi.LG_ERR_INVALID and b"no_such_option" in lib.lg_last_error()
-    assert lib.lg_engine_set_option(h, b"tail_variant", 1) == _cabi.LG_ERR_INVALID and b"experiment" in lib.lg_last_error()
+    assert lib.lg_engine_set_option(h, b"tail_variant", 1) == _cabi.LG_ERR_INVALID
     lib.lg_engine_destroy(h)
-    # precision enum: every named mode is accepted, anything past the last one is not
+    # precision enum: every named mode is accepted; the removed split-bf16 value (3) and anything past the last one are not
     for name, val in _cabi.LG_PREC.items():
         cfg = _cabi.LgConfig(256, 256, 9, 4, 0, 0.95, 0.99, 0.1, -1, val, -1)
         assert lib.lg_engine_create(ctypes.byref(cfg), ctypes.byref(h)) == _cabi.LG_OK, name
         lib.lg_engine_destroy(h)
-    cfg = _cabi.LgConfig(256, 256, 9, 4, 0, 0.95, 0.99, 0.1, -1, max(_cabi.LG_PREC.values()) + 1, -1)
-    assert lib.lg_engine_create(ctypes.byref(cfg), ctypes.byref(h)) == _cabi.LG_ERR_INVALID and b"precision" in lib.lg_last_error()
+    for val in (3, max(_cabi.LG_PREC.values()) + 1):
+        cfg = _cabi.LgConfig(256, 256, 9, 4, 0, 0.95, 0.99, 0.1, -1, val, -1)
+        assert lib.lg_engine_create(ctypes.byref(cfg), ctypes.byref(h)) == _cabi.LG_ERR_INVALID and b"precision" in lib.lg_last_error()
+    # attention precision: the linear precision itself, or one f16 plane together with f16x3 (the fast opt-in); nothing else
+    P = _cabi.LG_PREC
+    for prec, attn, want in ((P["f16x3"], P["f16x3"], _cabi.LG_OK), (P["f16x3"], P["fp16"], _cabi.LG_OK), (P["f16x3"], P["bf16"], _cabi.LG_ERR_INVALID),
+                             (P["fp32"], P["fp16"], _cabi.LG_ERR_INVALID), (P["bf16"], P["bf16"], _cabi.LG_OK)):
+        cfg = _cabi.LgConfig(256, 256, 9, 4, 0, 0.95, 0.99, 0.1, -1, prec, attn)
+        assert lib.lg_engine_create(ctypes.byref(cfg), ctypes.byref(h)) == want, (prec, attn)
+        if want == _cabi.LG_OK:
+            lib.lg_engine_destroy(h)

@@ -1,8 +1,10 @@
 """GPU parity: the HIP path (through the public class -> ctypes -> C ABI) against the golden vectors
 of the real reference and against the oracle.  Bar (BASELINE.json): indices bit-identical, scores
-within 1e-3.  "fp32" (exact f32 MFMA) must match everywhere; the default "bf16x3" (split-bf16 linear
-layers + f16 attention) must match except where the oracle sits within tolerance of a decision
-boundary, proven per element by conftest.explain_mismatches."""
+within 1e-3.  "fp32" (exact f32 MFMA) must match everywhere; the default "f16x3" (every contraction on
+split-f16 operands, attention included) must match except where the oracle sits within tolerance of a
+decision boundary, proven per element by conftest.explain_mismatches.  The fast opt-in ("f16x3/fp16":
+single-plane f16 attention) holds the same bar on the diffuse-attention fixtures and has its measured
+envelope asserted on the trained-statistics (recipe D) ones."""
 import numpy as np
 import pytest
 import torch
@@ -37,8 +39,11 @@ def test_fp32_mode_matches_golden_exactly(name):
     case, sd, data, gold, out = run_case(name, "fp32")
     np.testing.assert_array_equal(out["matches0"].cpu().numpy(), gold["matches0"])
     np.testing.assert_array_equal(out["matches1"].cpu().numpy(), gold["matches1"])
-    np.testing.assert_allclose(out["matching_scores0"].cpu().numpy(), gold["matching_scores0"], atol=2e-4, rtol=0)
-    np.testing.assert_allclose(out["matching_scores1"].cpu().numpy(), gold["matching_scores1"], atol=2e-4, rtol=0)
+    # fp32 summation order differs from torch's; on the recipe-D fixtures (residual rms 27, sharp softmax rows) that alone moves
+    # a score by up to 2.2e-4 (the numpy oracle itself: 1.4e-4) — still 4x inside the 1e-3 bar
+    atol = 5e-4 if name.startswith("trained_stats") else 2e-4
+    np.testing.assert_allclose(out["matching_scores0"].cpu().numpy(), gold["matching_scores0"], atol=atol, rtol=0)
+    np.testing.assert_allclose(out["matching_scores1"].cpu().numpy(), gold["matching_scores1"], atol=atol, rtol=0)
     stop = out["stop"] if not torch.is_tensor(out["stop"]) else out["stop"].cpu().tolist()
     assert np.atleast_1d(stop).tolist() == gold["stop"].tolist()
     np.testing.assert_array_equal(out["prune0"].cpu().numpy().astype(np.float32), gold["prune0"])
@@ -58,10 +63,11 @@ def test_fp32_mode_matches_golden_exactly(name):
 
 @pytest.mark.parametrize("name", golden_names())
 def test_default_precision_parity(name):
-    """bf16x3 against the reference's fixtures on BOTH image sides: scores within 1e-3, every index flip traced to an
-    oracle-side decision boundary within 2 x tolerance in score space; stop layers and both prune counters identical."""
+    """The default precision (f16x3, split attention) against the reference's fixtures — recipe D included — on BOTH image
+    sides: scores within 1e-3, every index flip traced to an oracle-side decision boundary within 2 x tolerance in score space;
+    stop layers and both prune counters identical."""
     require_gpu()
-    case, sd, data, gold, out = run_case(name, "bf16x3")
+    case, sd, data, gold, out = run_case(name, "f16x3")
     adaptive = case["conf"].get("depth_confidence", 0.95) > 0 or case["conf"].get("width_confidence", 0.99) > 0
     flips = assert_parity_with_explained_flips(out, gold, case, sd, data)
     if adaptive:
@@ -72,10 +78,30 @@ def test_default_precision_parity(name):
     np.testing.assert_array_equal(out["prune1"].cpu().numpy().astype(np.float32), gold["prune1"])
 
 
+@pytest.mark.parametrize("name", golden_names())
+def test_fast_attention_opt_in(name):
+    """precision f16x3 with attention_precision fp16 (one f16 plane for q / k / v, two MFMAs per product in their projections —
+    the round-2 default's arithmetic, ~25 % faster).  On the diffuse-attention fixtures (recipes A - C) it holds the full bar.
+    On the trained-statistics fixtures it does NOT: an f16 logit of magnitude 30 is off by 1e-2.  The measured envelope is
+    asserted so that the limit of the opt-in is documented: scores within 5e-2 where the index agrees, at most 1 % index flips."""
+    require_gpu()
+    case, sd, data, gold, out = run_case(name, "f16x3/fp16")
+    if not name.startswith("trained_stats"):
+        assert_parity_with_explained_flips(out, gold, case, sd, data)
+        stop = out["stop"] if not torch.is_tensor(out["stop"]) else out["stop"].cpu().tolist()
+        assert np.atleast_1d(stop).tolist() == gold["stop"].tolist()
+        return
+    for side in (0, 1):
+        m = out[f"matches{side}"].cpu().numpy(); sc = out[f"matching_scores{side}"].cpu().numpy()
+        same = m == gold[f"matches{side}"]
+        assert (~same).mean() <= 0.01
+        assert np.abs(sc - gold[f"matching_scores{side}"])[same].max(initial=0.0) <= 5e-2
+
+
 def test_fp16_mode_envelope_on_the_pruning_config():
     """BASELINE cfg #5 names fp16.  precision='fp16' (single f16 MFMA per product) does NOT hold the 1e-3 bar — the measured
     envelope on the cfg #5 fixture is asserted here so that it is documented, not hidden: scores within 3e-2, at most 1 % index
-    flips, stop layers identical.  (The parity-holding mode for this config is bf16x3, covered above.)"""
+    flips, stop layers identical.  (The parity-holding mode for this config is f16x3, covered above.)"""
     require_gpu()
     case, sd, data, gold, out = run_case("aliked128_2048x512_prune1536", "fp16")
     m0 = out["matches0"].cpu().numpy()
@@ -129,7 +155,7 @@ def test_nan_descriptors_do_not_fault_and_do_not_leak_into_other_pairs():
     sentinel of an all-NaN row must not be used as an index, and the other pairs must be untouched."""
     require_gpu()
     sd = synth.make_state_dict(0, recipe="A")
-    model = gpu_util.make_model(sd, "bf16x3", depth_confidence=-1, width_confidence=-1)
+    model = gpu_util.make_model(sd, "f16x3", depth_confidence=-1, width_confidence=-1)
     t = gpu_util.to_torch(synth.make_batch(41, 3, 300, 280))
     clean = model(t)
     t["image0"]["descriptors"][1] = float("nan")
@@ -173,7 +199,7 @@ def test_legacy_named_checkpoint_from_the_weights_directory():
 
 
 @pytest.mark.parametrize("fused", [False, True])
-@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16x3", 5e-4), ("fp16", 2e-2), ("bf16", 1e-1)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("f16x3", 5e-4), ("f16x3/fp16", 5e-4), ("fp16", 2e-2), ("bf16", 1e-1)])
 def test_pipeline_stages_layer0(precision, tol, fused):
     """Every kernel of layer 0 against the oracle's intermediate tensors (err relative to rms); once with
     the unfused per-op kernels (every intermediate is observable) and once with the fused block tail."""
@@ -181,7 +207,7 @@ def test_pipeline_stages_layer0(precision, tol, fused):
     sd = synth.make_state_dict(0, recipe="A")
     data = synth.make_batch(7, 2, 200, 160)
     res = gpu_util.stage_errors(sd, data, precision, dict(depth_confidence=-1, width_confidence=-1), fused=fused)
-    bad = {k: v for k, v in res.items() if not (v[1] <= (tol if not k.startswith(("self.q", "self.k", "self.v", "cross.qk", "cross.v")) else max(tol, {"fp32": 2e-5, "bf16x3": 3e-3, "fp16": 5e-3, "bf16": 5e-2}[precision])))}
+    bad = {k: v for k, v in res.items() if not (v[1] <= (tol if not k.startswith(("self.q", "self.k", "self.v", "cross.qk", "cross.v")) else max(tol, {"fp32": 2e-5, "f16x3": 5e-5, "f16x3/fp16": 3e-3, "fp16": 5e-3, "bf16": 5e-2}[precision])))}   # q / k / v in the attention's operand precision
     assert not bad, bad
 
 
@@ -192,7 +218,6 @@ def test_unfused_path_matches_golden():
     sd, data = make_golden.case_inputs(meta["case"])
     model = gpu_util.make_model(sd, "fp32", **meta["case"]["conf"])
     model.set_option("fused_tail", 0)
-    model.set_option("fused_proj", 0)
     out = model(gpu_util.to_torch(data))
     np.testing.assert_array_equal(out["matches0"].cpu().numpy(), gold["matches0"])
     np.testing.assert_allclose(out["matching_scores0"].cpu().numpy(), gold["matching_scores0"], atol=2e-4, rtol=0)
@@ -290,7 +315,7 @@ def test_ragged_batch_equals_per_pair_calls(mode):
 def test_match_batch_helper_trims_to_own_counts():
     require_gpu()
     sd = synth.make_state_dict(0, recipe="A")
-    model = gpu_util.make_model(sd, "bf16x3", depth_confidence=-1, width_confidence=-1)
+    model = gpu_util.make_model(sd, "f16x3", depth_confidence=-1, width_confidence=-1)
     from lightglue_amd import match_batch
     feats0, feats1, singles = [], [], []
     for b, (c0, c1) in enumerate([(140, 90), (64, 200)]):
@@ -334,7 +359,7 @@ def test_full_log_assignment_output(adaptive):
         assert la[b][333, 290] == 0.0
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16x3", 5e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("f16x3", 2e-3), ("f16x3/fp16", 5e-2)])
 def test_attention_deferred_rescale_with_sharp_logits(precision, tol):
     """The attention kernel rescales its running output only when a row's maximum grows by more than 2^8 (deferred
     rescale).  Random weights never exercise that branch after the first tile, so sharpen layer 0's logits (Wqkv x 60:
@@ -360,7 +385,7 @@ def test_attention_deferred_rescale_with_sharp_logits(precision, tol):
     assert res["self.attn_ctx"][1] <= tol, res["self.attn_ctx"]
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16x3/fp16", "bf16", "fp16"])
 def test_fused_next_projection_is_bit_identical(precision):
     """The tail kernel runs the next block's q/k/v projection on the x tile it has just produced (engine option
     fused_next, default on): same arithmetic on the same fp32 values as the standalone projection kernel, so every
@@ -381,11 +406,12 @@ def test_fused_next_projection_is_bit_identical(precision):
         assert torch.equal(torch.as_tensor(fused["stop"]), torch.as_tensor(plain["stop"]))
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16x3/fp16", "bf16"])
 def test_attention_rows_per_wave_variants_are_equivalent(precision):
     """Engine option attn_rows = 64 / 16 (four / one 16-row query tiles per wave; 256-row workgroup tiles are laid out
     per segment): same arithmetic per query row as the default 32-row kernel, so the outputs must be bit-identical — including
-    capacities that are not multiples of 256 (tiles overhang their segment and, for the last one, the row space)."""
+    capacities that are not multiples of 256 (tiles overhang their segment and, for the last one, the row space).  (The split
+    attention has the 32- and 16-row shapes; 64 maps to 32 there.)"""
     require_gpu()
     for (n0, n1, recipe, kw) in ((300, 333, "A", dict(depth_confidence=-1, width_confidence=-1)), (130, 520, "B", dict(pruning_min_kpts=64)),
                                  (1024, 1024, "A", dict(depth_confidence=-1, width_confidence=-1))):
@@ -401,13 +427,14 @@ def test_attention_rows_per_wave_variants_are_equivalent(precision):
         model.set_option("attn_rows", 32)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16x3/fp16", "bf16"])
 def test_attention_lds_dma_kernel_is_bit_identical(precision):
     """The default attention kernel brings K / V^T tiles into LDS by DMA (option attn_dma, default on; two buffers, one
     barrier per tile); with the option off the register-staged kernel runs.  Same arithmetic in the same order, so all outputs
     must be BIT-identical: key counts that end mid-tile, cross attention between unequal sets, one-tile key sets, adaptive
     runs with compaction — and a workspace that a previous call left full of NaN (a partial tile's dead V^T columns are
-    fixed up in LDS, they must never reach the MFMA)."""
+    fixed up in LDS, they must never reach the MFMA).  The split attention (f16x3) is always the DMA kernel: for it this test
+    is the NaN-poisoned-workspace check of its four-plane tile fix-up."""
     require_gpu()
     for (n0, n1, recipe, kw) in ((300, 333, "A", dict(depth_confidence=-1, width_confidence=-1)), (130, 520, "B", dict(pruning_min_kpts=64)),
                                  (1024, 1024, "A", dict(depth_confidence=-1, width_confidence=-1)), (40, 700, "C", dict())):
@@ -426,7 +453,7 @@ def test_attention_lds_dma_kernel_is_bit_identical(precision):
         assert torch.isfinite(dma["matching_scores0"]).all() and (dma["matches0"] > -1).any(), (n0, n1)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16x3/fp16", "bf16", "fp16"])
 def test_tail_row_tile_shapes_are_bit_identical(precision):
     """The fused tail runs 64-row workgroups when they fill the chip and 32- / 16-row ones for small grids (engine option
     tail_row_tiles: 0 = by grid fill, 4 | 2 | 1 = forced).  The per-row arithmetic and its order do not depend on the shape, so
@@ -452,7 +479,7 @@ def test_deferred_forward_gives_the_same_dict():
     results must equal the synchronous forwards' outputs (ragged lists included), in issue order and in reverse."""
     require_gpu()
     sd = synth.make_state_dict(0, recipe="C")
-    model = gpu_util.make_model(sd, "bf16x3")
+    model = gpu_util.make_model(sd, "f16x3")
     batches = [gpu_util.to_torch(synth.make_batch(41 + i, 2, 300 + 40 * i, 333)) for i in range(3)]
     want = [model(d) for d in batches]
     handles = [model.forward_deferred(d) for d in batches]
@@ -464,14 +491,6 @@ def test_deferred_forward_gives_the_same_dict():
         assert len(w["matches"]) == len(g["matches"]) and all(torch.equal(a, b) for a, b in zip(w["matches"], g["matches"]))
         assert all(torch.equal(a, b) for a, b in zip(w["scores"], g["scores"]))
     assert handles[0].result() is got[0]      # cached
-
-
-def test_product_library_has_no_experiment_variants():
-    """The streaming tail variants and the LG_* environment switches exist in experiment builds only (-DLG_EXPERIMENTS)."""
-    require_gpu()
-    model = gpu_util.make_model(synth.make_state_dict(0, recipe="A"), "fp32", depth_confidence=-1, width_confidence=-1)
-    with pytest.raises(Exception, match="experiment builds only"):
-        model.set_option("tail_variant", 1)
 
 
 def test_plain_bf16_mismatch_rate_is_reported_not_hidden():

@@ -12,7 +12,7 @@ from lightglue_amd import synthetic as synth
 pytestmark = pytest.mark.gpu
 
 
-def _model(precision="bf16x3", **kw):
+def _model(precision="f16x3", **kw):
     sd = synth.make_state_dict(0, recipe=kw.pop("recipe", "A"), input_dim=kw.get("input_dim", 256))
     return gpu_util.make_model(sd, precision, **kw)
 
@@ -124,7 +124,7 @@ def test_disk_4096_batch():
     """cfg #4-style shape on one GPU: 128-d, N=M=4096 (per-GPU shard of the 8-GPU batch, reduced to 4 pairs)."""
     require_gpu()
     sd = synth.make_state_dict(2, recipe="A", input_dim=128)
-    model = gpu_util.make_model(sd, "bf16x3", input_dim=128, depth_confidence=-1, width_confidence=-1)
+    model = gpu_util.make_model(sd, "f16x3", input_dim=128, depth_confidence=-1, width_confidence=-1)
     data = synth.make_batch(1000, 4, 4096, 4096, 128)
     out = model(gpu_util.to_torch(data))
     _check_structure(out, 4096, 4096)

@@ -21,7 +21,7 @@ KEYS = ("matches0", "matches1", "matching_scores0", "matching_scores1")
 
 
 def _model():
-    return gpu_util.make_model(synth.make_state_dict(0, recipe="A"), "bf16x3", depth_confidence=-1, width_confidence=-1)
+    return gpu_util.make_model(synth.make_state_dict(0, recipe="A"), "f16x3", depth_confidence=-1, width_confidence=-1)
 
 
 def _batch(ragged):

@@ -100,6 +100,6 @@ def test_extractor_feeds_the_matcher():
     f0 = ext.extract(img[0])
     f1 = ext.extract(torch.roll(img[0], shifts=(3, 5), dims=(-2, -1)))
     assert f0["keypoints"].shape == (1, 128, 2) and f0["descriptors"].shape == (1, 128, 256) and f0["image_size"].tolist() == [[160.0, 120.0]]
-    matcher = gpu_util.make_model(synth.make_state_dict(0, recipe="A"), "bf16x3", depth_confidence=-1, width_confidence=-1)
+    matcher = gpu_util.make_model(synth.make_state_dict(0, recipe="A"), "f16x3", depth_confidence=-1, width_confidence=-1)
     out = rbd(matcher({"image0": f0, "image1": f1}))
     assert out["matches0"].shape == (128,) and out["matches"].shape[1] == 2

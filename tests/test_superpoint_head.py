@@ -173,7 +173,7 @@ def test_detect_then_describe_then_match():
     kp, sc, num = H.detect_keypoints(torch.from_numpy(smap).cuda(), max_num_keypoints=256)
     desc = H.descriptor_head(kp, torch.from_numpy(dense).cuda(), 8, num)
     assert (desc[0, int(num[0]):] == 0).all()
-    model = gpu_util.make_model(synth.make_state_dict(0, recipe="A"), "bf16x3", depth_confidence=-1, width_confidence=-1)
+    model = gpu_util.make_model(synth.make_state_dict(0, recipe="A"), "f16x3", depth_confidence=-1, width_confidence=-1)
     size = torch.tensor([[128.0, 96.0]]).cuda()
     out = model({"image0": {"keypoints": kp[:1], "descriptors": desc[:1], "image_size": size, "num_keypoints": num[:1]},
                  "image1": {"keypoints": kp[1:], "descriptors": desc[1:], "image_size": size, "num_keypoints": num[1:]}})

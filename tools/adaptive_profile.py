@@ -10,7 +10,7 @@ import gpu_util
 from lightglue_amd import synthetic as synth
 B, n = 16, 2048
 sd = synth.make_state_dict(0, recipe="B")
-model = gpu_util.make_model(sd, "bf16x3", depth_confidence=-1, pruning_min_kpts=-1)   # pruning every layer, no early stop
+model = gpu_util.make_model(sd, "f16x3", depth_confidence=-1, pruning_min_kpts=-1)   # pruning every layer, no early stop
 data = gpu_util.to_torch(synth.make_batch(1, B, n, n))
 for _ in range(3): out = model(data)
 torch.cuda.synchronize()

@@ -8,7 +8,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import gpu_util
 from lightglue_amd import synthetic as synth
-prec = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
+prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 sd = synth.make_state_dict(0, recipe="A")
 model = gpu_util.make_model(sd, prec, depth_confidence=-1, width_confidence=-1)
 data = gpu_util.to_torch(synth.make_batch(1, 32, 1024, 1024))

@@ -9,7 +9,7 @@ sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import gpu_util
 from lightglue_amd import synthetic as synth
 sd = synth.make_state_dict(0, recipe="A")
-model = gpu_util.make_model(sd, "bf16x3", depth_confidence=-1, width_confidence=-1)
+model = gpu_util.make_model(sd, "f16x3", depth_confidence=-1, width_confidence=-1)
 data = gpu_util.to_torch(synth.make_batch(1, 32, 1024, 1024))
 for _ in range(3): model(data)
 model.set_option("tail_timing", 3); model(data); torch.cuda.synchronize()

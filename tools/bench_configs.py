@@ -10,15 +10,15 @@ from lightglue_amd import synthetic as synth
 
 CFGS = [
     ("#1 SuperPoint N=M=512 B=1 fp32 non-adaptive", dict(B=1, n=512, m=512, dim=256, prec="fp32", recipe="A", kw=dict(depth_confidence=-1, width_confidence=-1))),
-    ("#1' same, bf16x3", dict(B=1, n=512, m=512, dim=256, prec="bf16x3", recipe="A", kw=dict(depth_confidence=-1, width_confidence=-1))),
-    ("#2 SuperPoint N=M=1024 B=32 bf16x3 non-adaptive", dict(B=32, n=1024, m=1024, dim=256, prec="bf16x3", recipe="A", kw=dict(depth_confidence=-1, width_confidence=-1))),
-    ("#3 SuperPoint N=M=2048 adaptive (0.95/0.99) B=1 bf16x3, recipe C (mixed stop depths)", dict(B=1, n=2048, m=2048, dim=256, prec="bf16x3", recipe="C", kw=dict())),
-    ("#3' same, B=16", dict(B=16, n=2048, m=2048, dim=256, prec="bf16x3", recipe="C", kw=dict())),
-    ("#3b recipe B (every pair stops after 3 layers), B=16", dict(B=16, n=2048, m=2048, dim=256, prec="bf16x3", recipe="B", kw=dict())),
-    ("#3'' N=M=2048 NON-adaptive B=16 bf16x3 (for comparison)", dict(B=16, n=2048, m=2048, dim=256, prec="bf16x3", recipe="C", kw=dict(depth_confidence=-1, width_confidence=-1))),
-    ("#4 DISK 128-d N=M=4096 B=32 (one GPU's shard of 256) bf16x3", dict(B=32, n=4096, m=4096, dim=128, prec="bf16x3", recipe="A", kw=dict(depth_confidence=-1, width_confidence=-1, input_dim=128))),
+    ("#1' same, f16x3", dict(B=1, n=512, m=512, dim=256, prec="f16x3", recipe="A", kw=dict(depth_confidence=-1, width_confidence=-1))),
+    ("#2 SuperPoint N=M=1024 B=32 f16x3 non-adaptive", dict(B=32, n=1024, m=1024, dim=256, prec="f16x3", recipe="A", kw=dict(depth_confidence=-1, width_confidence=-1))),
+    ("#3 SuperPoint N=M=2048 adaptive (0.95/0.99) B=1 f16x3, recipe C (mixed stop depths)", dict(B=1, n=2048, m=2048, dim=256, prec="f16x3", recipe="C", kw=dict())),
+    ("#3' same, B=16", dict(B=16, n=2048, m=2048, dim=256, prec="f16x3", recipe="C", kw=dict())),
+    ("#3b recipe B (every pair stops after 3 layers), B=16", dict(B=16, n=2048, m=2048, dim=256, prec="f16x3", recipe="B", kw=dict())),
+    ("#3'' N=M=2048 NON-adaptive B=16 f16x3 (for comparison)", dict(B=16, n=2048, m=2048, dim=256, prec="f16x3", recipe="C", kw=dict(depth_confidence=-1, width_confidence=-1))),
+    ("#4 DISK 128-d N=M=4096 B=32 (one GPU's shard of 256) f16x3", dict(B=32, n=4096, m=4096, dim=128, prec="f16x3", recipe="A", kw=dict(depth_confidence=-1, width_confidence=-1, input_dim=128))),
     ("#5 ALIKED 128-d N=2048 M=512 B=64 fp16 adaptive, recipe C", dict(B=64, n=2048, m=512, dim=128, prec="fp16", recipe="C", wseed=2, kw=dict(input_dim=128))),
-    ("#5' same in bf16x3 (the parity-holding mode)", dict(B=64, n=2048, m=512, dim=128, prec="bf16x3", recipe="C", wseed=2, kw=dict(input_dim=128))),
+    ("#5' same in f16x3 (the parity-holding mode)", dict(B=64, n=2048, m=512, dim=128, prec="f16x3", recipe="C", wseed=2, kw=dict(input_dim=128))),
 ]
 lines = ["| config | pairs/s | ms/batch | mean stop | stop histogram (layers 1..9) | mean kept pts img0 (last layer) | matches/pair |", "|---|---|---|---|---|---|---|"]
 for name, c in CFGS:

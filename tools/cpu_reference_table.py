@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Time the UNMODIFIED reference (CPU fp32, B = 1, pruning / early stop off) and the numpy port (oracle/) side by side in the
+build container, at N = M = 512 and 1024 with 1 and 8 threads -> profiles/r03_cpu_reference.md.  The ratios feed
+bench.py's PORT_OVER_REFERENCE_TIME (the GPU box has no /root/reference, so bench.py times the port there and reports
+`reference_estimate_pairs_per_s = value x ratio` next to it).   usage: python tools/cpu_reference_table.py > profiles/r03_cpu_reference.md"""
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import bench  # noqa: E402
+from lightglue_amd import synthetic  # noqa: E402
+from oracle import lightglue_oracle as O  # noqa: E402
+from threadpoolctl import threadpool_limits  # noqa: E402
+
+sd = synthetic.make_state_dict(0, recipe="A")
+conf = O.make_conf(depth_confidence=-1, width_confidence=-1)
+print(f"# r03 — reference CPU path vs the numpy port, build container ({bench._cpu_model()}, {os.cpu_count()} logical cores)\n")
+print("`tools/cpu_reference_table.py`: unmodified `/root/reference/lightglue/lightglue.py` loaded standalone, CPU fp32, B = 1, recipe-A weights,")
+print("pruning / early stop off, 2 warm-up + 5 timed forwards; port = `oracle/lightglue_oracle.py` (`bench.py`'s timed CPU leg) under")
+print("`threadpool_limits`.\n")
+print("| N = M | threads | reference ms | reference pairs/s | port ms | port pairs/s | port / reference time |")
+print("|---|---|---|---|---|---|---|")
+ratios = {}
+for n in (512, 1024):
+    for th in (1, 8):
+        tr = bench._time_reference(sd, n, th, reps=5)
+        data = synthetic.make_batch(1, 1, n, n)
+        with threadpool_limits(limits=th):
+            bench.timed_port_forward(sd, conf, data, th)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                bench.timed_port_forward(sd, conf, data, th)
+            tp = (time.perf_counter() - t0) / 3
+        ratios[(n, th)] = tp / tr
+        print(f"| {n} | {th} | {tr * 1e3:.1f} | {1 / tr:.2f} | {tp * 1e3:.1f} | {1 / tp:.2f} | {tp / tr:.2f} |", flush=True)
+print("\nPORT_OVER_REFERENCE_TIME =", {f"{th} thread{'s' if th > 1 else ''}": {f"N={n}": round(ratios[(n, th)], 2) for n in (512, 1024)} for th in (1, 8)})

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-fixture PREDICTION (CPU emulation of the operand rounding, no GPU): max / rms |dscore| against the reference's golden
-vectors for the default precision ("bf16x3") and for "f16x3", to be compared with what tools/gpu_lab.py measures on the GPU.
+vectors for the default precision ("f16x3", split attention) and for the fast opt-in ("f16x3/fp16": one f16 plane for q / k / v / P), to be
+compared with what tools/gpu_lab.py measures on the GPU.
 usage: tools/emulated_margins.py [max keypoints per image, default 2048] > profiles/<round>_emulated_margins.md"""
 import sys
 import time
@@ -15,7 +16,7 @@ import make_golden  # noqa: E402
 from oracle import lightglue_oracle as O  # noqa: E402
 
 nmax = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-modes = {"bf16x3": O.DEFAULT_PRECISION_QUANT, "f16x3": {**O.DEFAULT_PRECISION_QUANT, "lin": "fp16x2", "final": "fp16x2"}}
+modes = {"f16x3": O.DEFAULT_PRECISION_QUANT, "f16x3/fp16": O.FAST_ATTENTION_QUANT}
 print("| fixture | " + " | ".join(f"{m}: idx flips / max / rms" for m in modes) + " |")
 print("|---|" + "---|" * len(modes))
 tot = {m: [0, 0.0, []] for m in modes}

@@ -10,7 +10,7 @@ from lightglue_amd import synthetic as synth
 import itertools
 for n, fused_next, variant, shape in [(512, 1, 0, 0), (512, 1, 0, 4), (1024, 1, 0, 0), (1024, 1, 0, 4), (1024, 1, 0, 2), (1024, 1, 0, 1), (2048, 1, 0, 0), (2048, 1, 0, 4), (2048, 1, 0, 1), (4096, 1, 0, 0), (4096, 1, 0, 4)]:
     sd = synth.make_state_dict(0, recipe="A")
-    model = gpu_util.make_model(sd, "bf16x3", depth_confidence=-1, width_confidence=-1)
+    model = gpu_util.make_model(sd, "f16x3", depth_confidence=-1, width_confidence=-1)
     model.set_option("fused_next", fused_next)
     model.set_option("tail_row_tiles", shape)
     if shape == 4: model.set_option("attn_rows", 32)   # the round-2 operating point: 64-row tail workgroups, 128-row attention workgroups

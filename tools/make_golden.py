@@ -56,6 +56,13 @@ CASES = {
     # padded with ones and masked, pruning off, early stop on; above the range nothing changes
     "static_lengths_256_512_in_range": dict(recipe="B", wseed=0, dseed=501, B=1, n=300, m=420, dim=256, prune_th=-1, static_lengths=[256, 512], conf=dict()),
     "static_lengths_256_512_above_range": dict(recipe="B", wseed=0, dseed=502, B=1, n=600, m=500, dim=256, prune_th=256, static_lengths=[256, 512], conf=dict()),
+    # ---- recipe D (round 3; VERDICT r02 "next" item 5): trained-model statistics — attention logit spread 25 per row, LayerNorm
+    # gains in [0.5, 4], residual rms growing to ~27, descriptor norms in [0.5, 3]; "DC" adds the adaptive-path edits
+    "trained_stats_512": dict(recipe="D", data="D", wseed=0, dseed=601, B=1, n=512, m=512, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1)),
+    "trained_stats_1024_filter0": dict(recipe="D", data="D", wseed=0, dseed=611, B=1, n=1024, m=1024, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1, filter_threshold=0.0)),
+    "trained_stats_2048": dict(recipe="D", data="D", wseed=0, dseed=621, B=1, n=2048, m=2048, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1)),
+    "trained_stats_adaptive_1024": dict(recipe="DC", data="D", wseed=0, dseed=631, B=2, n=1024, m=1024, dim=256, prune_th=-1, conf=dict()),
+    "trained_stats_adaptive_2048_th1536": dict(recipe="DC", data="D", wseed=0, dseed=641, B=2, n=2048, m=2048, dim=256, prune_th=1536, conf=dict()),
 }
 
 
@@ -78,7 +85,8 @@ def case_inputs(case: dict):
                     "image_size": np.tile(np.array([[1024.0, 768.0]], np.float32), (case["B"], 1))}
         data = {"image0": img(case["n"]), "image1": img(case["m"])}
     else:
-        data = synth.make_batch(case["dseed"], case["B"], case["n"], case["m"], case["dim"], add_scale_ori=conf.get("add_scale_ori", False))
+        data_kw = dict(synth.RECIPE_D_DATA) if case.get("data") == "D" else {}
+        data = synth.make_batch(case["dseed"], case["B"], case["n"], case["m"], case["dim"], add_scale_ori=conf.get("add_scale_ori", False), **data_kw)
     if case.get("no_size"):
         for k in ("image0", "image1"):
             data[k].pop("image_size")

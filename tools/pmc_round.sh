@@ -9,4 +9,5 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w -- python bench.py 
 python tools/rocpd_pmc.py $(find $OUT/sq -name "*.db" | head -1) $OUT/pmc_sq.md | head -12
 python tools/rocpd_pmc.py $(find $OUT/fetch -name "*.db" | head -1) $OUT/pmc_fetch.md | grep -i "sweep\|tail_kernel\|attn\|sim_kernel"
 python tools/rocpd_pmc.py $(find $OUT/write -name "*.db" | head -1) $OUT/pmc_write.md | grep -i "sweep\|tail_kernel\|attn\|sim_kernel"
+python tools/pmc_traffic.py $(find $OUT/fetch -name "*.db" | head -1) $(find $OUT/write -name "*.db" | head -1) f16x3/f16x3/B32/N1024 | tail -20; cp profiles/pmc_traffic.json $OUT/
 find $OUT -name "*.db" -delete

@@ -7,7 +7,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import gpu_util
 from lightglue_amd import synthetic as synth
-prec = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
+prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 1   # 1 = fused tail, 2 = self projection
 sd = synth.make_state_dict(0, recipe="A")
 model = gpu_util.make_model(sd, prec, depth_confidence=-1, width_confidence=-1)

@@ -9,9 +9,9 @@ import gpu_util
 from lightglue_amd import synthetic as synth
 case = sys.argv[1]
 if case == "adaptive_b16_n2048":      # cfg #3', recipe C: mixed stop depths, pruning active
-    sd = synth.make_state_dict(0, recipe="C"); model = gpu_util.make_model(sd, "bf16x3"); data = synth.make_batch(1, 16, 2048, 2048)
+    sd = synth.make_state_dict(0, recipe="C"); model = gpu_util.make_model(sd, "f16x3"); data = synth.make_batch(1, 16, 2048, 2048)
 elif case == "b1_n1024":              # single pair, non-adaptive: the small-grid kernel shapes
-    sd = synth.make_state_dict(0, recipe="A"); model = gpu_util.make_model(sd, "bf16x3", depth_confidence=-1, width_confidence=-1); data = synth.make_batch(1, 1, 1024, 1024)
+    sd = synth.make_state_dict(0, recipe="A"); model = gpu_util.make_model(sd, "f16x3", depth_confidence=-1, width_confidence=-1); data = synth.make_batch(1, 1, 1024, 1024)
 else:
     raise SystemExit("unknown case")
 data = gpu_util.to_torch(data)

@@ -99,10 +99,12 @@ def flops_per_pair(n: int, m: int) -> float:
     return L * (per_pt_layer * (n + m) + 4 * D * (n * n + m * m) + 6 * D * n * m) + 2 * D * D * (n + m) + 2 * D * n * m
 
 
-# time ratio numpy-port / real reference measured in the build container (8 vCPU Intel Xeon @ 2.10 GHz, torch 2.10 CPU, fp32,
-# N=M=1024 / 512, B=1, pruning off; /root/reference loaded standalone as tools/make_golden.py does): the port is the slower
-# stand-in, so the reference's own CPU rate on this host is about `value` x ratio
-PORT_OVER_REFERENCE_TIME = {"1 thread": {"N=512": 1.35, "N=1024": 1.30}, "8 threads": {"N=512": 3.5, "N=1024": 4.2}}
+# time ratio numpy-port / real reference, measured side by side in the build container (profiles/r03_cpu_reference.md,
+# tools/cpu_reference_table.py: 8 vCPU Intel Xeon @ 2.10 GHz, torch 2.10 CPU fp32, B = 1, pruning off; /root/reference loaded
+# standalone as tools/make_golden.py does).  The port is the slower stand-in — its GEMMs are as fast, but numpy runs softmax / erf /
+# LayerNorm on one core and OpenBLAS threads the attention's batched 64-deep matmuls 5x SLOWER than one thread — so the reference's
+# own CPU rate on the same cores is about `value` x ratio (reported as cpu_baseline.reference_estimate_pairs_per_s)
+PORT_OVER_REFERENCE_TIME = {"1 thread": {"N=512": 1.45, "N=1024": 1.58}, "8 threads": {"N=512": 4.90, "N=1024": 6.54}}
 REFERENCE_FILE = Path("/root/reference/lightglue/lightglue.py")
 
 
@@ -138,50 +140,10 @@ def _time_reference(sd, n, threads, reps, warm=2):
         torch.set_num_threads(old)
 
 
-class _ParallelElementwise:
-    """Timed CPU leg only: numpy runs the port's elementwise / row-wise passes (softmax exp over 4 N^2 values per attention call,
-    erf-GELU, LayerNorm, log-softmax) on ONE core while torch parallelises them in the real reference, which made the port 4-5x
-    slower than the reference at 8 threads although its GEMMs are as fast.  Inside this context the oracle's
-    row-wise helpers run on row chunks in a thread pool (numpy ufuncs release the GIL).  Every row is still computed by the
-    same numpy code, so results are bit-identical to the plain oracle (tests/test_host_api.py checks that); the checker used
-    by the tests is the unpatched module."""
-    NAMES = ("_softmax", "_log_softmax", "_gelu", "_layernorm")
-
-    def __init__(self, threads):
-        self.threads = max(1, int(threads))
-
-    def __enter__(self):
-        from concurrent.futures import ThreadPoolExecutor
-        from oracle import lightglue_oracle as O
-        self.O, self.saved = O, {k: getattr(O, k) for k in self.NAMES}
-        if self.threads > 1:
-            self.pool = ThreadPoolExecutor(self.threads)
-            for k, fn in self.saved.items():
-                setattr(O, k, self._wrap(fn))
-        return self
-
-    def __exit__(self, *exc):
-        for k, fn in self.saved.items():
-            setattr(self.O, k, fn)
-        if self.threads > 1:
-            self.pool.shutdown()
-
-    def _wrap(self, fn):
-        pool, parts = self.pool, self.threads
-
-        def run(x, *a, **k):
-            rows = x.shape[-2] if x.ndim >= 2 else 0
-            if rows < 4 * parts or k.get("axis", a[0] if a and isinstance(a[0], int) else -1) not in (-1, x.ndim - 1):
-                return fn(x, *a, **k)
-            cut = np.linspace(0, rows, parts + 1).astype(int)
-            return np.concatenate(list(pool.map(lambda i: fn(x[..., cut[i]:cut[i + 1], :], *a, **k), range(parts))), axis=-2)
-        return run
-
-
 def timed_port_forward(sd, conf, data, threads):
+    """One forward of the numpy port (oracle/) — the timed CPU leg and, with the same call, the checker of the GPU batch."""
     from oracle import lightglue_oracle as O
-    with _ParallelElementwise(threads):
-        return O.forward(sd, conf, data)
+    return O.forward(sd, conf, data)
 
 
 def _port_over_reference(n, threads):
@@ -229,9 +191,8 @@ def cpu_baseline(sd, n, m, gpu_out=None, budget_s=12.0, max_pairs=8):
             t1 = time.perf_counter(); timed_port_forward(sd, conf, d512, th); timed_port_forward(sd, conf, d512, th)
             cfg1[f"{th} thread(s)"] = round(2.0 / (time.perf_counter() - t1), 3)
     res = {"value": done / dt, "unit": "image-pairs/s", "cores": best, "kind": "port",
-           "sample": f"{done} pair(s) N=M={n} of the benchmark's own batch, 9 layers, fp32 numpy/OpenBLAS port of the reference CPU path "
-                     f"(row-wise passes chunked over the same {best} threads), {dt:.1f}s, "
-                     f"{best} thread(s) (fastest of 1/8/16/32 on {ncpu} logical cores)",
+           "sample": f"{done} pair(s) N=M={n} of the benchmark's own batch, 9 layers, fp32 numpy/OpenBLAS port of the reference CPU path, {dt:.1f}s, "
+                     f"{best} BLAS thread(s) (fastest of 1/8/16/32 on {ncpu} logical cores)",
            "cpu_model": _cpu_model(), "logical_cores": ncpu,
            "cfg1_n512_b1_pairs_per_s": cfg1,
            "port_over_reference_time_ratio": PORT_OVER_REFERENCE_TIME,

@@ -370,10 +370,8 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_dma_kernel(AttnArgs a) {
         char* bK = smem + buf * BUFB; char* bV = bK + TILEB;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kseg + (long long)kv0 * 64 + koff[i]),
-                                             (__attribute__((address_space(3))) void*)(bK + (2 * wave + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vrow[i] + kv0),
-                                             (__attribute__((address_space(3))) void*)(bV + (2 * wave + i) * 1024), 16, 0, 0);
+            lds_dma16(kseg + (long long)kv0 * 64 + koff[i], bK + (2 * wave + i) * 1024);
+            lds_dma16(vrow[i] + kv0, bV + (2 * wave + i) * 1024);
         }
     };
     dma_tile(0, 0);
@@ -432,7 +430,7 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_dma_kernel(AttnArgs a) {
             }
             __syncthreads();
         }
-        if (tile + 1 < ntiles) dma_tile((tile + 1) & 1, kv0 + ABK);
+        dma_tile((tile + 1) & 1, tile + 1 < ntiles ? kv0 + ABK : kv0);   // not branched (see attn_split_kernel); the last tile re-fetches itself into the idle buffer
         __builtin_amdgcn_sched_barrier(0);
         ATT_TICK(1);
 
@@ -514,6 +512,7 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_dma_kernel(AttnArgs a) {
         }
         ATT_TICK(5);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last (redundant) tile fetch must have landed before this wave's LDS can be released
 #ifdef LG_ATTN_TIMING
     if (a.dbg && lane == 0) {
         long long* d = a.dbg + ((long long)blockIdx.x * 4 + wave) * 8;
@@ -550,13 +549,18 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_dma_kernel(AttnArgs a) {
 // spread reaches 25 (recipe-D fixtures, DESIGN.md §1: QK^T alone 1.4e-2, P V alone 5e-3; split: 5e-5 / < 5e-4).  There is no cheaper
 // operand format with >= 17 bits on gfx950 (no xf32; fp32 MFMA runs at 1/16 of the f16 rate).
 // Structure = attn_dma_kernel: LDS-DMA tiles, two buffers, one barrier per tile, wave priority by progress, scores accumulated
-// from -m_run.  A buffer holds four 8 KB tiles (K hi, K lo, V^T hi, V^T lo): 64 KB per workgroup, two workgroups per CU, two
-// waves per SIMD (<= 256 VGPRs).  QT = 16-row query tiles per wave: 2 (128-row workgroups) or 1 for under-filled grids.
-template <int QT>
-__global__ __launch_bounds__(ATHREADS, 2) void attn_split_kernel(AttnArgs a) {
+// from -m_run.  A buffer holds four 8 KB tiles (K hi, K lo, V^T hi, V^T lo): 64 KB per workgroup, two workgroups per CU.
+// QT = 16-row query tiles per wave, NW = waves per workgroup.  Shapes (round-3 A/B at cfg #2, one box each): 8 waves x 16 rows
+// (108 VGPRs, four waves per SIMD; the product shape, and 4 x 16 rows = 64-row workgroups for under-filled grids) is 2-3 % faster
+// than 4 waves x 32 rows (172 VGPRs, two waves per SIMD).  Lost: a cross-tile software pipeline (S(t+1) MFMAs interleaved with the
+// softmax VALU of tile t inside each wave via sched_group_barrier: bit-identical, +7 % time).  SQ counters of the kernel: matrix
+// pipe 54 % busy, waves 42 % issue-stalled, 25 % parked; timing ablations: no DMA -9 %, no exponentials -4 % — LAB_NOTES.md.
+template <int QT, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void attn_split_kernel(AttnArgs a) {
     typedef TagF16 Tag;
     typedef f16_t T;
-    constexpr int ABM = 64 * QT, ROWB = 128, TILEB = 64 * ROWB, BUFB = 4 * TILEB;
+    constexpr int NT = NW * 64, PPW = 8 / NW;      // threads; DMA pieces per wave per (plane, tile)
+    constexpr int ABM = 16 * QT * NW, ROWB = 128, TILEB = 64 * ROWB, BUFB = 4 * TILEB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int ntile = gridDim.x >> 2;
@@ -576,36 +580,35 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_split_kernel(AttnArgs a) {
     const T* Vt = static_cast<const T*>(a.vt);
 
     if (kvlen == 0) {  // ref :114-115: empty key set -> zeros
-        for (int i = tid; i < ABM * 16; i += ATHREADS) {
+        for (int i = tid; i < ABM * 16; i += NT) {
             const int row = i >> 4, c4 = i & 15;
             if (t.r0 + row < qlen) *reinterpret_cast<f32x4*>(a.ctx + (t.grow0 + row) * 256LL + head * 64 + c4 * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         return;
     }
 
-    // DMA source offsets (elements), per lane: piece p = 2 * wave + i covers rows 8p .. 8p + 7 of each of the four tiles
+    // DMA source offsets (elements), per lane: piece p = PPW * wave + i covers rows 8p .. 8p + 7 of each of the four tiles
     const int prow = lane >> 3, pslot = lane & 7;
-    int koff[2], voff[2];
+    int koff[PPW], voff[PPW];
+    const T* vrow[PPW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (2 * wave + i) * 8 + prow;
+    for (int i = 0; i < PPW; ++i) {
+        const int row = (PPW * wave + i) * 8 + prow;
         koff[i] = row * 64 + ((pslot ^ (((row >> 1) & 1) | (((row >> 3) & 3) << 1))) << 3);          // inverse of k_off<128>
         voff[i] = (pslot ^ ((row >> 1) & 7)) << 3;                                                      // inverse of lds_off<128>; + row * R below
     }
     const T* kseg = Kp + ((long long)head * R + kvbase) * 64;
-    const T* vrow[2] = {Vt + ((long long)head * 64 + (2 * wave) * 8 + prow) * R + kvbase + voff[0],
-                        Vt + ((long long)head * 64 + (2 * wave + 1) * 8 + prow) * R + kvbase + voff[1]};
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) vrow[i] = Vt + ((long long)head * 64 + (PPW * wave + i) * 8 + prow) * R + kvbase + voff[i];
     auto dma_tile = [&](int buf, int kv0) {
         char* bK = smem + buf * BUFB;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < PPW; ++i) {
             const T* ks = kseg + (long long)kv0 * 64 + koff[i];
             const T* vs = vrow[i] + kv0;
-            char* dst = bK + (2 * wave + i) * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ks + PL), (__attribute__((address_space(3))) void*)(dst + TILEB), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs, (__attribute__((address_space(3))) void*)(dst + 2 * TILEB), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vs + PL), (__attribute__((address_space(3))) void*)(dst + 3 * TILEB), 16, 0, 0);
+            char* dst = bK + (PPW * wave + i) * 1024;
+            lds_dma16(ks, dst); lds_dma16(ks + PL, dst + TILEB);
+            lds_dma16(vs, dst + 2 * TILEB); lds_dma16(vs + PL, dst + 3 * TILEB);
         }
     };
     dma_tile(0, 0);
@@ -638,6 +641,9 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_split_kernel(AttnArgs a) {
     }
 
     const int ntiles = (kvlen + ABK - 1) / ABK;
+#ifdef LG_ATTN_TIMING
+    long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+#endif
     for (int tile = 0; tile < ntiles; ++tile) {
         const int kv0 = tile * ABK;
         const char* bK = smem + (tile & 1) * BUFB;
@@ -647,17 +653,48 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_split_kernel(AttnArgs a) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of this tile (and, first time round, my Q fragments)
         __syncthreads();
+        ATT_TICK(0);
         if (kv0 + ABK > kvlen) {                            // workgroup-uniform: zero the dead key columns of both V^T planes
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = tid + ATHREADS * (i & 1), row = c >> 3, slot = c & 7;
-                u32x4* p = reinterpret_cast<u32x4*>(const_cast<char*>(bK) + (2 + (i >> 1)) * TILEB + lds_off<ROWB>(row, slot));
+            for (int i = 0; i < 1024 / NT; ++i) {         // 512 16-byte chunks per plane
+                const int c = (tid + NT * i) & 511, plane = (tid + NT * i) >> 9, row = c >> 3, slot = c & 7;
+                u32x4* p = reinterpret_cast<u32x4*>(const_cast<char*>(bK) + (2 + plane) * TILEB + lds_off<ROWB>(row, slot));
                 *p = mask_tail<Tag>(*p, kvlen - (kv0 + slot * 8));
             }
             __syncthreads();
         }
-        if (tile + 1 < ntiles) dma_tile((tile + 1) & 1, kv0 + ABK);
+        // Fragment reads are software-pipelined one group ahead of the MFMAs (two register sets; sched_barrier pins the order —
+        // hipcc otherwise sinks every ds_read next to its use and each group of 12 MFMAs starts with an exposed LDS round trip,
+        // 16 of them per tile, with only two waves per SIMD to cover).  Group = (k-chunk, pair of key tiles) for S^T and
+        // (P chunk, pair of d tiles) for O^T; the first V^T group is fetched during the last K group, so that its latency
+        // hides under the softmax.
+        u32x4 fh[2][2], fl[2][2];
+        auto load_k = [&](int grp, u32x4 (&h)[2], u32x4 (&l)[2]) {
+            const int c = grp >> 1, kp = grp & 1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int kt = 2 * kp + j;
+                const char* src = bK + kfo[c] + (32 * (kt >> 1) + 4 * (kt & 1)) * ROWB;   // key row 32 (kt >> 1) + 8 (lr >> 2) + 4 (kt & 1) + (lr & 3)
+                h[j] = *reinterpret_cast<const u32x4*>(src);
+                l[j] = *reinterpret_cast<const u32x4*>(src + TILEB);
+            }
+        };
+        auto load_v = [&](int grp, u32x4 (&h)[2], u32x4 (&l)[2]) {
+            const int tp = grp >> 1, dp = grp & 1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const char* src = bK + vfo[tp] + (2 * dp + j) * 16 * ROWB;
+                h[j] = *reinterpret_cast<const u32x4*>(src);
+                l[j] = *reinterpret_cast<const u32x4*>(src + TILEB);
+            }
+        };
+        load_k(0, fh[0], fl[0]);
+        // NOT branched around: hipcc merges its s_waitcnt bookkeeping conservatively at a join, and every fragment wait of the tile
+        // became lgkmcnt(0) — i.e. the prefetched group was waited for as well (measured in the ISA).  The last tile re-fetches
+        // itself into the idle buffer instead; the wave drains vmcnt before it leaves the loop (no DMA may land after the exit).
+        dma_tile((tile + 1) & 1, tile + 1 < ntiles ? kv0 + ABK : kv0);
         __builtin_amdgcn_sched_barrier(0);
+        ATT_TICK(1);
 
         // ---- S^T - m_run: per k-chunk and pair of key tiles, three products over 2 x QT independent accumulators
         f32x4 s[4][QT];
@@ -666,31 +703,28 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_split_kernel(AttnArgs a) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{-m_run[qt], -m_run[qt], -m_run[qt], -m_run[qt]};
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int grp = 0; grp < 4; ++grp) {
+            const int c = grp >> 1, kp = grp & 1;
+            if (grp < 3) load_k(grp + 1, fh[(grp + 1) & 1], fl[(grp + 1) & 1]);
+            else load_v(0, fh[0], fl[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 (&kh)[2] = fh[grp & 1];
+            const u32x4 (&kl)[2] = fl[grp & 1];
 #pragma unroll
-            for (int kp = 0; kp < 2; ++kp) {
-                u32x4 kh[2], kl[2];
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int kt = 2 * kp + j;
-                    const char* src = bK + kfo[c] + (32 * (kt >> 1) + 4 * (kt & 1)) * ROWB;   // key row 32 (kt >> 1) + 8 (lr >> 2) + 4 (kt & 1) + (lr & 3)
-                    kh[j] = *reinterpret_cast<const u32x4*>(src);
-                    kl[j] = *reinterpret_cast<const u32x4*>(src + TILEB);
-                }
+                for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(s[2 * kp + j][qt], kh[j], ql[qt][c]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(s[2 * kp + j][qt], kh[j], ql[qt][c]);
+                for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(s[2 * kp + j][qt], kl[j], qh[qt][c]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(s[2 * kp + j][qt], kl[j], qh[qt][c]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(s[2 * kp + j][qt], kh[j], qh[qt][c]);
-            }
+                for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(s[2 * kp + j][qt], kh[j], qh[qt][c]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        ATT_TICK(2);
         if (kv0 + ABK > kvlen) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt)
@@ -725,6 +759,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_split_kernel(AttnArgs a) {
                 for (int kt = 0; kt < 4; ++kt) s[kt][qt] -= shift;
             }
         }
+        ATT_TICK(3);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             float rs0 = 0.f, rs1 = 0.f;
@@ -737,36 +772,44 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_split_kernel(AttnArgs a) {
             }
             l_run[qt] += rs0 + rs1;
         }
+        ATT_TICK(4);
         // ---- O^T += V^T P^T with P = Ph + Pl (both f16; the residual p - Ph is exact in fp32): three products per (d tile, query tile)
+        u32x4 ph[2][QT], pl[2][QT];
 #pragma unroll
-        for (int tp = 0; tp < 2; ++tp) {
-            u32x4 ph[QT], pl[QT];
+        for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) split8_f16<true>(s[2 * tp][qt], s[2 * tp + 1][qt], ph[qt], pl[qt]);
+            for (int qt = 0; qt < QT; ++qt) split8_f16<true>(s[2 * tp][qt], s[2 * tp + 1][qt], ph[tp][qt], pl[tp][qt]);
 #pragma unroll
-            for (int dp = 0; dp < 2; ++dp) {
-                u32x4 vh[2], vl[2];
+        for (int grp = 0; grp < 4; ++grp) {
+            const int tp = grp >> 1, dp = grp & 1;
+            if (grp < 3) load_v(grp + 1, fh[(grp + 1) & 1], fl[(grp + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 (&vh)[2] = fh[grp & 1];
+            const u32x4 (&vl)[2] = fl[grp & 1];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const char* src = bK + vfo[tp] + (2 * dp + j) * 16 * ROWB;
-                    vh[j] = *reinterpret_cast<const u32x4*>(src);
-                    vl[j] = *reinterpret_cast<const u32x4*>(src + TILEB);
-                }
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(o[2 * dp + j][qt], vh[j], pl[tp][qt]);
 #pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(o[2 * dp + j][qt], vh[j], pl[qt]);
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(o[2 * dp + j][qt], vl[j], ph[tp][qt]);
 #pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(o[2 * dp + j][qt], vl[j], ph[qt]);
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(o[2 * dp + j][qt], vh[j], ph[qt]);
-            }
+                for (int qt = 0; qt < QT; ++qt) mma_chunk<Tag>(o[2 * dp + j][qt], vh[j], ph[tp][qt]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        ATT_TICK(5);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last (redundant) tile fetch must have landed before this wave's LDS can be released
+#ifdef LG_ATTN_TIMING
+    if (a.dbg && lane == 0) {
+        long long* d = a.dbg + ((long long)blockIdx.x * NW + wave) * 8;
+        for (int i = 0; i < 6; ++i) d[i] = tacc[i];
+        d[6] = ntiles; d[7] = 1;
+    }
+#endif
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         float l = l_run[qt];
@@ -781,14 +824,14 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_split_kernel(AttnArgs a) {
     }
 }
 
-template <int QT> static hipError_t launch_attn_split(const AttnArgs& a, hipStream_t s) {
+template <int QT, int NW> static hipError_t launch_attn_split(const AttnArgs& a, hipStream_t s) {
     if (a.plane <= 0) return hipErrorInvalidValue;
     constexpr int smem = 2 * 4 * 64 * 128;
-    auto kern = attn_split_kernel<QT>;
+    auto kern = attn_split_kernel<QT, NW>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
-    const int tiles = a.rs.B * (a.rs.cap0 + a.rs.cap1) / (64 * QT);
-    hipLaunchKernelGGL(kern, dim3(tiles * 4), dim3(ATHREADS), smem, s, a);
+    const int tiles = a.rs.B * (a.rs.cap0 + a.rs.cap1) / (16 * QT * NW);
+    hipLaunchKernelGGL(kern, dim3(tiles * 4), dim3(NW * 64), smem, s, a);
     return hipGetLastError();
 }
 
@@ -815,7 +858,7 @@ hipError_t launch_attention(int attn_prec, const AttnArgs& a, hipStream_t s) {
         case PREC_F32: return launch_attn_t<TagF32, 2>(a, s);
         case PREC_BF16: if (a.dma && rpw == 32) return launch_attn_dma<TagBF16>(a, s); return rpw == 64 ? launch_attn_t<TagBF16, 4>(a, s) : rpw == 16 ? launch_attn_t<TagBF16, 1>(a, s) : launch_attn_t<TagBF16, 2>(a, s);
         case PREC_F16: if (a.dma && rpw == 32) return launch_attn_dma<TagF16>(a, s); return rpw == 64 ? launch_attn_t<TagF16, 4>(a, s) : rpw == 16 ? launch_attn_t<TagF16, 1>(a, s) : launch_attn_t<TagF16, 2>(a, s);
-        case PREC_F16X3: return rpw == 16 ? launch_attn_split<1>(a, s) : launch_attn_split<2>(a, s);
+        case PREC_F16X3: return rpw == 16 ? launch_attn_split<1, 4>(a, s) : launch_attn_split<1, 8>(a, s);   // 64-row workgroups for under-filled grids, else 128-row ones (8 waves x 16 rows)
     }
     return hipErrorInvalidValue;
 }

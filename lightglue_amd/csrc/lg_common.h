@@ -123,6 +123,18 @@ template <int ROWB> __device__ __forceinline__ int lds_off(int row, int slot16) 
     else return row * 256 + ((slot16 ^ (row & 15)) << 4);
 }
 
+// ---- LDS-DMA: one wave moves 64 x 16 B (1 KB) from global memory straight into LDS; lane l's 16 bytes land at lds + 16 l.
+// As inline asm ON PURPOSE: through the builtin (__builtin_amdgcn_global_load_lds) hipcc's s_waitcnt pass books the instruction as
+// a FLAT access that may touch LDS, and while one is in flight EVERY later LDS wait becomes lgkmcnt(0) — a fragment prefetched for
+// the next group of MFMAs is then waited for together with the current one (seen in the ISA of the attention kernels: 8 exposed LDS
+// round trips per 64-key tile).  The asm form is invisible to that pass; completion is tracked by hand (s_waitcnt vmcnt before the
+// barrier that publishes the tile), and a compiler-issued vmcnt wait can only over-wait because of it, never under-wait.
+// `lds` must be wave-uniform (it travels in M0); one wait state between the M0 write and the DMA instruction.
+__device__ __forceinline__ void lds_dma16(const void* gptr, void* lds) {
+    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(gptr) : "memory", "m0");
+}
+
 // ---- row space
 struct RowSpace {
     int B;            // pairs in this forward

@@ -209,19 +209,3 @@ def test_weight_changes_invalidate_the_packed_copy():
     m.refresh_weights()
     assert m._weights_sig is None
 
-
-def test_timed_cpu_port_is_bit_identical_to_the_checker():
-    """bench.py's timed CPU leg runs the oracle's row-wise passes (softmax, log-softmax, LayerNorm, GELU) on row chunks in a
-    thread pool; every row is still computed by the same numpy code, so the result must equal the plain oracle bit for bit."""
-    import bench
-    from lightglue_amd import synthetic as synth
-    from oracle import lightglue_oracle as O
-
-    sd = synth.make_state_dict(0, recipe="A")
-    conf = O.make_conf(depth_confidence=-1, width_confidence=-1)
-    data = synth.make_batch(3, 1, 200, 150)
-    plain = O.forward(sd, conf, data)
-    pooled = bench.timed_port_forward(sd, conf, data, 4)
-    for k in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
-        np.testing.assert_array_equal(np.asarray(plain[k]), np.asarray(pooled[k]))
-    assert O._softmax.__module__ == "oracle.lightglue_oracle"   # the patch is gone after the timed leg

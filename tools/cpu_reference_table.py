@@ -29,10 +29,10 @@ for n in (512, 1024):
         tr = bench._time_reference(sd, n, th, reps=5)
         data = synthetic.make_batch(1, 1, n, n)
         with threadpool_limits(limits=th):
-            bench.timed_port_forward(sd, conf, data, th)
+            O.forward(sd, conf, data)
             t0 = time.perf_counter()
             for _ in range(3):
-                bench.timed_port_forward(sd, conf, data, th)
+                O.forward(sd, conf, data)
             tp = (time.perf_counter() - t0) / 3
         ratios[(n, th)] = tp / tr
         print(f"| {n} | {th} | {tr * 1e3:.1f} | {1 / tr:.2f} | {tp * 1e3:.1f} | {1 / tp:.2f} | {tp / tr:.2f} |", flush=True)

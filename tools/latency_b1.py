@@ -14,8 +14,6 @@ for n, fused_next, variant, shape in [(512, 1, 0, 0), (512, 1, 0, 4), (1024, 1, 
     model.set_option("fused_next", fused_next)
     model.set_option("tail_row_tiles", shape)
     if shape == 4: model.set_option("attn_rows", 32)   # the round-2 operating point: 64-row tail workgroups, 128-row attention workgroups
-    if variant:
-        model.set_option("tail_variant", variant)   # experiment builds only (lg_tail4.hip)
     data = gpu_util.to_torch(synth.make_batch(1, 1, n, n))
     for _ in range(5): model(data)
     torch.cuda.synchronize(); t0 = time.perf_counter(); reps = 50

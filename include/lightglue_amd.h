@@ -167,9 +167,9 @@ int lg_sp_sample_descriptors(const float* desc_map, int32_t batch, int32_t chann
 /* ---- SuperPoint conv stack (replaces superpoint.py:127-141 layers and :159-184, :213-214 of forward) ----
  * lg_sp_pack_conv_weight: repack one nn.Conv2d weight [cout][cin][k][k] (device fp32) into the layout the kernels read,
  *   [k*k][cout][cin] (conv1a: [9][64]); dst holds cout*cin*k*k floats.
- * lg_sp_encode: image [batch][1][h][w] fp32 (grayscale, h and w multiples of 8) ->
- *   scores   [batch][h][w]            keypoint probabilities after softmax / dustbin removal / depth-to-space (ref :176-184),
- *                                      the input of lg_sp_detect
+ * lg_sp_encode: image [batch][1][h][w] fp32 (grayscale, any h, w >= 8: the 2x2 max-pools floor like nn.MaxPool2d) ->
+ *   scores   [batch][h/8*8][w/8*8]    keypoint probabilities after softmax / dustbin removal / depth-to-space (ref :176-184),
+ *                                      i.e. cropped to whole 8 x 8 cells like the reference's; the input of lg_sp_detect
  *   desc_map [batch][256][h/8][w/8]   RAW convDb output (NCHW), the input of lg_sp_sample_descriptors(normalize_dense = 1)
  *   params: 24 device pointers = (packed weight, bias) of conv1a, conv1b, conv2a, conv2b, conv3a, conv3b, conv4a, conv4b,
  *           convPa, convPb, convDa, convDb; workspace: lg_sp_encode_workspace_bytes(batch, h, w) bytes.

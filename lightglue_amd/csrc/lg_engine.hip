@@ -575,7 +575,7 @@ int64_t lg_sp_encode_workspace_bytes(int32_t batch, int32_t h, int32_t w) {
 
 int lg_sp_encode(const float* image, int32_t batch, int32_t h, int32_t w, const float* const* params, void* workspace,
                  int64_t workspace_bytes, float* scores, float* desc_map, void* hip_stream) {
-    if (batch < 1 || h < 8 || w < 8 || (h & 7) || (w & 7)) return fail(LG_ERR_INVALID, "image height / width must be positive multiples of 8");
+    if (batch < 1 || h < 8 || w < 8) return fail(LG_ERR_INVALID, "image height / width must be at least 8");
     if (!image || !params || !workspace || !scores || !desc_map) return fail(LG_ERR_INVALID, "null pointer");
     if (workspace_bytes < lg_sp_encode_workspace_bytes(batch, h, w)) return fail(LG_ERR_INVALID, "workspace too small (lg_sp_encode_workspace_bytes)");
     for (int i = 0; i < 24; ++i) if (!params[i]) return fail(LG_ERR_INVALID, "null layer parameter");

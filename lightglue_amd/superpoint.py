@@ -70,7 +70,8 @@ class SuperPoint(nn.Module):
     @torch.no_grad()
     def encode(self, image: torch.Tensor):
         """image [B, 1, H, W] (or [B, 3, H, W]: converted like kornia's rgb_to_grayscale, ref :155-156) ->
-        (scores [B, H, W], dense raw descriptors [B, 256, H/8, W/8]) — ref :159-184 and :213-214."""
+        (scores [B, H // 8 * 8, W // 8 * 8], dense raw descriptors [B, 256, H // 8, W // 8]) — ref :159-184 and :213-214.  Any
+        H, W >= 8: the three 2 x 2 max-pools floor like the reference's nn.MaxPool2d, so the score map is cropped to whole 8 x 8 cells."""
         if image.device.type != "cuda":
             raise RuntimeError("lightglue_amd.SuperPoint runs on MI355X (ROCm device type 'cuda') only; there is no CPU fallback. "
                                f"Got an image on {image.device}.")
@@ -81,13 +82,13 @@ class SuperPoint(nn.Module):
         device = image.device
         image = image.detach().to(dtype=torch.float32).contiguous()
         bsz, _, h, w = image.shape
-        assert h % 8 == 0 and w % 8 == 0, "image height and width must be multiples of 8"
+        assert h >= 8 and w >= 8, "image must be at least 8 x 8"
         lib = _cabi.load()
         params = self._params(device)
         arr = (C.c_void_p * 24)(*[t.data_ptr() for t in params])
         nbytes = lib.lg_sp_encode_workspace_bytes(bsz, h, w)
         work = torch.empty((nbytes,), device=device, dtype=torch.uint8)
-        scores = torch.empty((bsz, h, w), device=device, dtype=torch.float32)
+        scores = torch.empty((bsz, h // 8 * 8, w // 8 * 8), device=device, dtype=torch.float32)
         dense = torch.empty((bsz, 256, h // 8, w // 8), device=device, dtype=torch.float32)
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
@@ -108,13 +109,18 @@ class SuperPoint(nn.Module):
         kpts, kscores, counts = detect_keypoints(scores, c.nms_radius, c.remove_borders, c.detection_threshold, c.max_num_keypoints)
         nmax = int(counts.max().item()) if counts.numel() else 0
         kpts, kscores = kpts[:, :nmax].contiguous(), kscores[:, :nmax].contiguous()
+        if bool((counts < nmax).any()):   # ragged batch: rows beyond an image's count are padding — zero them (descriptor_head does the same)
+            live = torch.arange(nmax, device=counts.device)[None, :] < counts[:, None]
+            kpts = kpts * live[..., None]; kscores = kscores * live
         desc = descriptor_head(kpts, dense, 8, counts)
         return {"keypoints": kpts, "keypoint_scores": kscores, "descriptors": desc, "num_keypoints": counts}   # counts: consumed by LightGlue.forward
 
     @torch.no_grad()
     def extract(self, img: torch.Tensor, **conf) -> dict:
-        """ref utils.py:136-147 without the resize step (ImagePreprocessor is out of scope): the image is used at its own size,
-        so scales = 1 and the keypoints already live in its pixel frame; `image_size` = (w, h) is attached for the matcher."""
+        """ref utils.py:136-147 WITHOUT the resize step: the reference's Extractor.extract first resizes the long side to 1024
+        (ImagePreprocessor, kornia — out of scope here); this method uses the image at its own size, so on the same file it
+        detects at a different scale than the reference unless the caller resizes first.  scales = 1, the keypoints already live
+        in the image's pixel frame; `image_size` = (w, h) is attached for the matcher."""
         if img.dim() == 3:
             img = img[None]
         assert img.dim() == 4 and img.shape[0] == 1

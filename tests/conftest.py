@@ -61,10 +61,11 @@ def explain_mismatches(got_m0, got_s0, ref, score_tol=SCORE_TOL, filter_threshol
     unexplained = 0
 
     def near_tie(vec):
+        # a tie only matters where the winner can become a match at all: top score at or above the filter threshold
         if vec.size < 2:
             return False
         top2 = np.sort(vec)[-2:]
-        return float(np.exp(top2[1]) - np.exp(top2[0])) <= 2 * score_tol
+        return float(np.exp(top2[1])) > filter_threshold - score_tol and float(np.exp(top2[1]) - np.exp(top2[0])) <= 2 * score_tol
 
     for a in diff:
         near_thr = abs(float(ref_s[a]) - filter_threshold) <= score_tol or abs(float(got_s0[a]) - filter_threshold) <= score_tol
@@ -74,7 +75,14 @@ def explain_mismatches(got_m0, got_s0, ref, score_tol=SCORE_TOL, filter_threshol
             pa = int(np.where(own == a)[0][0])
             row = S[pa]
             if near_tie(row) or near_tie(S[:, int(row.argmax())]):
-                continue
+                # the flipped keypoint's own score must still be the oracle's score of whatever it picked (0 when unmatched)
+                if got_m0[a] == -1:
+                    want = 0.0
+                else:
+                    pb = np.where(other == got_m0[a])[0]
+                    want = float(np.exp(row[int(pb[0])])) if pb.size else None
+                if want is not None and abs(float(got_s0[a]) - want) <= 2 * score_tol:
+                    continue
         unexplained += 1
     return unexplained
 
@@ -92,7 +100,7 @@ def assert_parity_with_explained_flips(out, gold, case, sd, data, score_tol=SCOR
         bad = np.abs(s - gs) > score_tol
         flips = m != gm
         # a score may differ by more than the tolerance only where the index legitimately flipped (the score then belongs
-        # to another partner, or drops to 0 when mutuality is lost)
+        # to another partner, or drops to 0 when mutuality is lost); explain_mismatches bounds the flipped keypoint's score too
         assert not (bad & ~flips).any(), f"side {side}: {int((bad & ~flips).sum())} scores off by more than {score_tol} without an index flip"
         for b in np.where(flips.any(axis=1))[0]:
             if b not in traces:

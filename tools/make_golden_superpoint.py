@@ -105,6 +105,9 @@ def reference_detect(ref, scores: torch.Tensor, nms_radius=4, remove_borders=4, 
 ENCODE_CASES = {
     "superpoint_full_b1_120x160": (0, 10, 1, 120, 160, None),
     "superpoint_full_b2_64x96_top50": (1, 11, 2, 64, 96, 50),
+    # height / width NOT multiples of 8: floor max-pooling, score map cropped to (H // 8 * 8, W // 8 * 8) — what the
+    # reference's Extractor.extract produces for most real images after its resize (e.g. 1024 x 683)
+    "superpoint_full_b1_75x109_top40": (2, 12, 1, 75, 109, 40),
 }
 
 
@@ -184,7 +187,10 @@ def reference_encode(model, image: torch.Tensor):
 def main():
     ref = load_reference_functions()
     out_dir0 = ROOT / "tests" / "golden"
+    only = set(sys.argv[1:])
     for name, (wseed, iseed, b, h, w, topk) in ENCODE_CASES.items():
+        if only and name not in only:
+            continue
         sd = encoder_state_dict(wseed)
         model = load_reference_superpoint(sd, max_num_keypoints=topk)
         img = torch.from_numpy(encoder_image(iseed, b, h, w))
@@ -199,6 +205,8 @@ def main():
         np.savez_compressed(out_dir0 / f"{name}.npz", **arrays)
         print(name, "scores", tuple(sc.shape), "max", float(sc.max()), "keypoints", None if "keypoints" not in arrays else arrays["keypoints"].shape)
     out_dir = ROOT / "tests" / "golden"
+    if only:
+        return
     for name, (seed, b, h, w, topk) in DETECT_CASES.items():
         smap = score_map(seed, b, h, w)
         with torch.no_grad():

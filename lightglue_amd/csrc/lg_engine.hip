@@ -182,6 +182,24 @@ int upload_fragment_packed(int prec, const std::vector<double>& W, int rows, int
     return LG_OK;
 }
 
+// Row order of the fragment-packed q/k/v projection weights (lg_proj_body.h pj_tile): n-tile t, MFMA row i -> packed column
+// ([group][head][64]).  The n_qk leading groups of 16 tiles each (q, k / qk) are dealt in PAIRS of adjacent tiles whose 32 rows are
+// interleaved in blocks of 4 — tile 2p + e, row 4g + r <- channel 32p + 8g + 4e + r — so that a lane of the transposed MFMA form
+// ends with 8 consecutive channels (one 16-byte store per plane); v tiles keep the natural order.
+std::vector<double> proj_row_permutation(const std::vector<float>& pw, int nout, int n_qk_groups, int K) {
+    std::vector<double> out((size_t)nout * K);
+    for (int t = 0; t < nout / 16; ++t)
+        for (int i = 0; i < 16; ++i) {
+            int col = t * 16 + i;
+            if (t < 16 * n_qk_groups) {
+                const int group = t / 16, tg = t % 16;
+                col = group * 256 + 32 * (tg / 2) + 8 * (i >> 2) + 4 * (tg % 2) + (i & 3);
+            }
+            for (int k = 0; k < K; ++k) out[(size_t)(t * 16 + i) * K + k] = pw[(size_t)col * K + k];
+        }
+    return out;
+}
+
 const HostTensor* find(const lg_engine* e, const std::string& name, std::initializer_list<int64_t> shape, std::string& err) {
     auto it = e->staged.find(name);
     if (it == e->staged.end()) { err = "missing weight '" + name + "'"; return nullptr; }
@@ -429,7 +447,7 @@ int lg_engine_finalize_weights(lg_engine* e) {
                 std::memcpy(&pw[(size_t)dst * D], &w->data[(size_t)src * D], D * 4);
                 pb[dst] = b->data[src];
             }
-            TRY(upload_fragment_packed(prec, std::vector<double>(pw.begin(), pw.end()), 768, D, e->w_sqkv_p + (size_t)i * sqkv_layer));
+            TRY(upload_fragment_packed(prec, proj_row_permutation(pw, 768, 2, D), 768, D, e->w_sqkv_p + (size_t)i * sqkv_layer));
             TRY(up_f32(e->b_sqkv + (size_t)i * 768, pb.data(), 768));
         }
         {
@@ -482,7 +500,7 @@ int lg_engine_finalize_weights(lg_engine* e) {
             std::memcpy(pw.data(), wq->data.data(), (size_t)D * D * 4);
             std::memcpy(pw.data() + (size_t)D * D, wv->data.data(), (size_t)D * D * 4);
             std::memcpy(pb.data(), bq->data.data(), D * 4); std::memcpy(pb.data() + D, bv->data.data(), D * 4);
-            TRY(upload_fragment_packed(prec, std::vector<double>(pw.begin(), pw.end()), 512, D, e->w_cqkv_p + (size_t)i * cqkv_layer));
+            TRY(upload_fragment_packed(prec, proj_row_permutation(pw, 512, 1, D), 512, D, e->w_cqkv_p + (size_t)i * cqkv_layer));
             TRY(up_f32(e->b_cqkv + (size_t)i * 512, pb.data(), 512));
             TRY(upload_packed(prec, wo->data.data(), (size_t)D * D, e->w_cout, (size_t)i * D * D));
             TRY(up_f32(e->b_cout + (size_t)i * D, bo->data.data(), D));

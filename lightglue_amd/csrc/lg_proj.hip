@@ -37,7 +37,7 @@ __global__ __launch_bounds__(PTHREADS) void proj_kernel(ProjArgs a) {
         for (int st = 0; st < STAGES; ++st)
 #pragma unroll
             for (int j = 0; j < NV; ++j) hreg[st][j] = *reinterpret_cast<const f32x4*>(src + st * KE + 4 * j);
-        const int off = lds_off<128>(srow, sslot);
+        const int off = pj_tile_off(srow, sslot);
 #pragma unroll
         for (int st = 0; st < STAGES; ++st) {
             char* tile = smA + st * TILE;

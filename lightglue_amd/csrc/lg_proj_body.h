@@ -2,7 +2,7 @@
 // (lg_proj.hip) and by the fused tail (lg_tail.hip), which runs the NEXT block's projection on the x tile it has
 // just produced instead of writing it out and launching a second kernel.
 // Precondition: the 64 x 256 activation tile sits in LDS at smA in operand precision ([NPART planes][STAGES][64][128 B],
-// XOR-swizzled with lds_off<128>) and NO barrier has been executed since those writes (proj_compute issues its weight
+// XOR-swizzled with pj_tile_off) and NO barrier has been executed since those writes (proj_compute issues its weight
 // prefetch first and then synchronises).
 #pragma once
 #include "lg_kernels.h"
@@ -54,15 +54,34 @@ template <int PREC> struct PJL {   // LDS geometry of the activation tile
     static constexpr int A_PLANE = STAGES * TILE;      // 32 KB (16-bit) / 64 KB (f32)
     static constexpr int A_BYTES = PJ<PREC>::APART * A_PLANE;
 };
-// One pass of the projection: NTP n-tiles per wave (wave w owns the n-tiles w + 8*jj, jj = PASS*NTP + j, i.e. the 16 output
-// columns w*16 + 128*jj ...).  The column group of a tile (q / k / v, or qk / v) is jj >> 1 — a compile-time constant — and decides
-// the FORM of the tile's MFMAs:
+// Which n-tile of the packed weights slot j of pass `pass` is for wave w, and of which kind.  Self (768 columns = q | k | v groups of
+// 16 n-tiles, NTP = 3): pass p = the wave's PAIR of adjacent tiles of group p (q, then k) + one v tile; cross (512 columns = qk | v,
+// NTP = 2): pass 0 = the qk pair, pass 1 = two v tiles.  A q / k pair is the two tiles 2w, 2w + 1 of its group = 32 consecutive head
+// channels, and the host packs their 32 weight rows so that MFMA row 4g + r of tile e holds channel 8g + 4e + r (lg_engine.hip
+// proj_row_permutation): in the transposed form lane (lr, g) then ends with 8 CONSECUTIVE channels 8g .. 8g + 7 of keypoint row lr —
+// one 16-byte store per plane instead of two 8-byte ones (the projection epilogues were store-issue bound: 48 dwordx2 stores per wave).
+// Keypoint ROWS are dealt the same way between pairs of 16-row tiles (MT >= 2): MFMA row slot i of m-tile 2q + e is keypoint row
+// 32q + 8 (i >> 2) + 4e + (i & 3) of the workgroup's tile — a lane of a plain-form v tile (row slots 4g .. 4g + 3 of channel lr) then
+// holds rows 8g .. 8g + 7 over the pair: one 16-byte store into the [head][64][R] layout.  A free choice (which LDS row a lane reads);
+// the activation tile uses the swizzle of the attention's K tile (k-chunk slot ^ row bits 1, 3, 4), which is conflict-free for
+// exactly this row pattern.
+template <int MT> __device__ __forceinline__ int pj_row(int mt, int slot) {
+    if constexpr (MT >= 2) return 32 * (mt >> 1) + 8 * (slot >> 2) + 4 * (mt & 1) + (slot & 3);
+    else return slot;
+}
+__device__ __forceinline__ int pj_tile_off(int row, int slot16) { return row * 128 + ((slot16 ^ (((row >> 1) & 1) | (((row >> 3) & 3) << 1))) << 4); }
+template <int NTP> __device__ __forceinline__ constexpr bool pj_is_v(int pass, int j) { return NTP == 3 ? j == 2 : pass == 1; }
+template <int NTP> __device__ __forceinline__ int pj_tile(int w, int pass, int j) {
+    if constexpr (NTP == 3) return j < 2 ? 16 * pass + 2 * w + j : 32 + w + 8 * pass;
+    else return pass == 0 ? 2 * w + j : 16 + w + 8 * j;
+}
+// One pass of the projection.  The kind of a tile decides the FORM of its MFMAs:
 //   q / k tiles: TRANSPOSED, C^T = W x^T (weights as the A operand): lane (lr, g) ends with keypoint row lr of the 16-row tile
-//     and the 4 consecutive head channels 4g..4g+3 -> bias as one float4, the rotary pair (2j, 2j+1) sits in one lane (no
-//     cross-lane traffic, ref :58-65), and the result leaves as ONE 8-byte (16-bit q/k) store per 16-row tile: lanes g = 0..3
-//     cover 32 contiguous bytes of a [row][64] line.
-//   v tiles: plain C = x W^T: lane (lr, g) holds channel lr of rows 4g..4g+3 -> one 8-byte store into the transposed
-//     [head][64][R] layout (4 consecutive rows of one channel).
+//     and 4 consecutive head channels per tile -> bias as float4s, the rotary pair (2j, 2j+1) sits in one lane (no cross-lane
+//     traffic, ref :58-65), and the pair's 8 channels leave as ONE 16-byte store per plane: lanes g = 0..3 cover 64 contiguous
+//     bytes of a [row][64] line.
+//   v tiles: plain C = x W^T: lane (lr, g) holds channel lr of row slots 4g..4g+3 = rows 8g..8g+7 over a pair of m-tiles (pj_row)
+//     -> one 16-byte store per plane into the transposed [head][64][R] layout (8 consecutive rows of one channel).
 // Nothing is staged through LDS and no barrier follows the MFMA loop (the staged version spent 40 % of the kernel in its two
 // epilogues: LDS write, barrier, LDS read, store, barrier).
 template <int PREC, class TA, int NTP, int NPASS, int PASS, int A_PLANE, int MT>
@@ -72,7 +91,6 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
     constexpr int NPART = PJ<PREC>::NPART, APART = PJ<PREC>::APART;
     constexpr int STAGES = PJL<PREC>::STAGES, NKC = 2 * STAGES, TILE = MT * 16 * 128;   // one plane of one K stage: MT*16 rows x 128 B
     constexpr int NBUF = NPART == 2 ? 2 : 4;
-    constexpr int N_QK = NTP == 3 ? 2 : 1;             // self: q, k, v groups of 256 columns; cross: qk, v
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, g = lane >> 4;
     const long long R = a.R;
     auto stamp = [&](int slot) {   // profiling tap (a.dbg == nullptr in production)
@@ -86,7 +104,7 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
 #pragma unroll
         for (int j = 0; j < NTP; ++j)
 #pragma unroll
-            for (int p = 0; p < NPART; ++p) dst[j][p] = wfrag(p, w + 8 * (pass * NTP + j), kc);
+            for (int p = 0; p < NPART; ++p) dst[j][p] = wfrag(p, pj_tile<NTP>(w, pass, j), kc);
     };
     f32x4 acc[MT][NTP];
 #pragma unroll
@@ -112,13 +130,12 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
             for (int mt = 0; mt < MG; ++mt)
 #pragma unroll
                 for (int p = 0; p < APART; ++p)
-                    afh[mt][p] = *reinterpret_cast<const u32x4*>(tile + p * A_PLANE + lds_off<128>((mh + mt) * 16 + lr, (kc & 1) * 4 + g));
+                    afh[mt][p] = *reinterpret_cast<const u32x4*>(tile + p * A_PLANE + pj_tile_off(pj_row<MT>(mh + mt, lr), (kc & 1) * 4 + g));
 #pragma unroll
             for (int mtl = 0; mtl < MG; ++mtl)
 #pragma unroll
                 for (int j = 0; j < NTP; ++j) {
-                    const bool is_v = ((PASS * NTP + j) >> 1) >= N_QK;     // compile-time after unrolling
-                    if (is_v) pj_mma<PREC, false>(acc[mh + mtl][j], bf[i][j], afh[mtl]);
+                    if (pj_is_v<NTP>(PASS, j)) pj_mma<PREC, false>(acc[mh + mtl][j], bf[i][j], afh[mtl]);   // compile-time after unrolling
                     else pj_mma<PREC, true>(acc[mh + mtl][j], bf[i][j], afh[mtl]);
                 }
             }
@@ -132,71 +149,86 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
     typedef TA ta4 __attribute__((ext_vector_type(4)));
     constexpr int OPART = PJ<PREC>::OPART;
     static_assert(OPART == 1 || sizeof(TA) == 2, "split q / k / v planes are f16");
-    f32x4 b4[NTP]; float bv[NTP];
-    f32x2 c2[NTP][MT], s2[NTP][MT];
+    constexpr bool HAS_PAIR = !pj_is_v<NTP>(PASS, 0);          // slots 0, 1 = a q / k pair
+    constexpr bool ROPE = NTP == 3;                            // SelfBlock: rotary on q and k (ref :58-65)
+    const int pcol = (NTP == 3 ? PASS * 256 : 0) + 32 * w;     // first packed column of the pair: [group][head][64]
+    f32x4 pb[2]; f32x4 pc[MT], ps[MT]; float bv[NTP];
+    if constexpr (HAS_PAIR) {
+        pb[0] = *reinterpret_cast<const f32x4*>(a.bias + pcol + 8 * g); pb[1] = *reinterpret_cast<const f32x4*>(a.bias + pcol + 8 * g + 4);
+        if constexpr (ROPE) {
 #pragma unroll
-    for (int j = 0; j < NTP; ++j) {
-        constexpr int dummy = 0; (void)dummy;
-        const int jj = PASS * NTP + j;
-        const int col0 = (w + 8 * jj) * 16, d0 = col0 & 63;
-        if ((jj >> 1) < N_QK) {
-            b4[j] = *reinterpret_cast<const f32x4*>(a.bias + col0 + 4 * g);
-            if constexpr (NTP == 3) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const long long row = t.grow0 + mt * 16 + lr;
-                    c2[j][mt] = *reinterpret_cast<const f32x2*>(a.cosb + row * 32 + (d0 >> 1) + 2 * g);
-                    s2[j][mt] = *reinterpret_cast<const f32x2*>(a.sinb + row * 32 + (d0 >> 1) + 2 * g);
-                }
+            for (int mt = 0; mt < MT; ++mt) {
+                const long long row = t.grow0 + pj_row<MT>(mt, lr);
+                pc[mt] = *reinterpret_cast<const f32x4*>(a.cosb + row * 32 + ((pcol & 63) >> 1) + 4 * g);
+                ps[mt] = *reinterpret_cast<const f32x4*>(a.sinb + row * 32 + ((pcol & 63) >> 1) + 4 * g);
             }
-        } else {
-            bv[j] = a.bias[col0 + lr];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NTP; ++j)
+        if (pj_is_v<NTP>(PASS, j)) bv[j] = a.bias[pj_tile<NTP>(w, PASS, j) * 16 + lr];
+    if constexpr (HAS_PAIR) {                                  // q / k (or qk) pair: 8 consecutive channels per lane and keypoint row
+        TA* base = static_cast<TA*>((NTP == 3 && PASS == 1) ? a.k : a.q);
+        const int head = (pcol >> 6) & 3, d0 = pcol & 63;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const long long row = t.grow0 + pj_row<MT>(mt, lr);
+            f32x4 v0 = acc[mt][0] + pb[0], v1 = acc[mt][1] + pb[1];
+            if constexpr (ROPE) {                              // pairs (2f, 2f+1) with frequency f
+                const f32x4 c = pc[mt], sn = ps[mt];
+                const f32x4 u0 = v0, u1 = v1;
+                v0[0] = u0[0] * c[0] - u0[1] * sn[0]; v0[1] = u0[1] * c[0] + u0[0] * sn[0];
+                v0[2] = u0[2] * c[1] - u0[3] * sn[1]; v0[3] = u0[3] * c[1] + u0[2] * sn[1];
+                v1[0] = u1[0] * c[2] - u1[1] * sn[2]; v1[1] = u1[1] * c[2] + u1[0] * sn[2];
+                v1[2] = u1[2] * c[3] - u1[3] * sn[3]; v1[3] = u1[3] * c[3] + u1[2] * sn[3];
+            }
+            v0 *= QK_PRESCALE; v1 *= QK_PRESCALE;
+            TA* dst = base + ((long long)head * R + row) * 64 + d0 + 8 * g;
+            if constexpr (OPART == 2) {                        // hi plane + lo plane (f16 of the residual, exact subtraction in fp32)
+                u32x4 hi, lo;
+                split8_f16<true>(v0, v1, hi, lo);
+                *reinterpret_cast<u32x4*>(dst) = hi;
+                *reinterpret_cast<u32x4*>(dst + a.plane) = lo;
+            } else if constexpr (sizeof(TA) == 2) {
+                *reinterpret_cast<u32x4*>(dst) = pack8<Tag>(v0, v1);
+            } else {
+                *reinterpret_cast<f32x4*>(dst) = v0; *reinterpret_cast<f32x4*>(dst + 4) = v1;
+            }
         }
     }
 #pragma unroll
     for (int j = 0; j < NTP; ++j) {
-        constexpr int dummy = 0; (void)dummy;
-        const int jj = PASS * NTP + j;
-        const int col0 = (w + 8 * jj) * 16;               // first output column of the tile
-        const int group = jj >> 1, head = (col0 >> 6) & 3, d0 = col0 & 63;
-        if (group < N_QK) {                               // q / k (or qk): transposed tile
-            TA* base = static_cast<TA*>(group == 0 ? a.q : a.k);
+        if (!pj_is_v<NTP>(PASS, j)) continue;                  // v: plain tile -> transposed layout [head][64][R]
+        const int col0 = pj_tile<NTP>(w, PASS, j) * 16;        // first packed column of the tile
+        const int head = (col0 >> 6) & 3, d0 = col0 & 63;
+        TA* vrow = static_cast<TA*>(a.vt) + ((long long)head * 64 + d0 + lr) * R + t.grow0;
+        if constexpr (MT >= 2) {                               // rows 8g .. 8g + 7 of a pair of m-tiles: 16-byte stores
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const long long row = t.grow0 + mt * 16 + lr;
-                f32x4 v = acc[mt][j] + b4[j];
-                if constexpr (NTP == 3) {                 // SelfBlock: rotary, pairs (2f, 2f+1) with frequency f (ref :58-65)
-                    const f32x2 c = c2[j][mt], sn = s2[j][mt];
-                    const f32x4 u = v;
-                    v[0] = u[0] * c[0] - u[1] * sn[0]; v[1] = u[1] * c[0] + u[0] * sn[0];
-                    v[2] = u[2] * c[1] - u[3] * sn[1]; v[3] = u[3] * c[1] + u[2] * sn[1];
-                }
-                v *= QK_PRESCALE;
-                TA* dst = base + ((long long)head * R + row) * 64 + d0 + 4 * g;
-                if constexpr (OPART == 2) {               // hi plane + lo plane (f16 of the residual, exact subtraction in fp32)
-                    uint32_t h01, l01, h23, l23;
-                    split2_f16(v[0], v[1], h01, l01); split2_f16(v[2], v[3], h23, l23);
-                    *reinterpret_cast<u32x2*>(dst) = u32x2{h01, h23};
-                    *reinterpret_cast<u32x2*>(dst + a.plane) = u32x2{l01, l23};
+            for (int q = 0; q < MT / 2; ++q) {
+                const f32x4 v0 = acc[2 * q][j] + bv[j], v1 = acc[2 * q + 1][j] + bv[j];
+                TA* dst = vrow + 32 * q + 8 * g;
+                if constexpr (OPART == 2) {
+                    u32x4 hi, lo;
+                    split8_f16<true>(v0, v1, hi, lo);
+                    *reinterpret_cast<u32x4*>(dst) = hi;
+                    *reinterpret_cast<u32x4*>(dst + a.plane) = lo;
+                } else if constexpr (sizeof(TA) == 2) {
+                    *reinterpret_cast<u32x4*>(dst) = pack8<Tag>(v0, v1);
                 } else {
-                    ta4 o = {pj_cvt<TA>(v[0]), pj_cvt<TA>(v[1]), pj_cvt<TA>(v[2]), pj_cvt<TA>(v[3])};
-                    *reinterpret_cast<ta4*>(dst) = o;
+                    *reinterpret_cast<f32x4*>(dst) = v0; *reinterpret_cast<f32x4*>(dst + 4) = v1;
                 }
             }
-        } else {                                          // v: plain tile -> transposed layout [head][64][R]
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const f32x4 v = acc[mt][j] + bv[j];
-                TA* dst = static_cast<TA*>(a.vt) + ((long long)head * 64 + d0 + lr) * R + t.grow0 + mt * 16 + 4 * g;
-                if constexpr (OPART == 2) {
-                    uint32_t h01, l01, h23, l23;
-                    split2_f16(v[0], v[1], h01, l01); split2_f16(v[2], v[3], h23, l23);
-                    *reinterpret_cast<u32x2*>(dst) = u32x2{h01, h23};
-                    *reinterpret_cast<u32x2*>(dst + a.plane) = u32x2{l01, l23};
-                } else {
-                    ta4 o = {pj_cvt<TA>(v[0]), pj_cvt<TA>(v[1]), pj_cvt<TA>(v[2]), pj_cvt<TA>(v[3])};
-                    *reinterpret_cast<ta4*>(dst) = o;
-                }
+        } else {
+            const f32x4 v = acc[0][j] + bv[j];
+            TA* dst = vrow + 4 * g;
+            if constexpr (OPART == 2) {
+                uint32_t h01, l01, h23, l23;
+                split2_f16(v[0], v[1], h01, l01); split2_f16(v[2], v[3], h23, l23);
+                *reinterpret_cast<u32x2*>(dst) = u32x2{h01, h23};
+                *reinterpret_cast<u32x2*>(dst + a.plane) = u32x2{l01, l23};
+            } else {
+                ta4 o = {pj_cvt<TA>(v[0]), pj_cvt<TA>(v[1]), pj_cvt<TA>(v[2]), pj_cvt<TA>(v[3])};
+                *reinterpret_cast<ta4*>(dst) = o;
             }
         }
     }
@@ -221,7 +253,7 @@ __device__ __forceinline__ void proj_compute(const ProjArgs& a, const TileLoc& t
 #pragma unroll
             for (int p = 0; p < NPART; ++p) {
                 const char* ptr = static_cast<const char*>(a.W) + (p ? (long long)a.Nout * 256 * (long long)sizeof(typename Tag::elem) : 0);
-                bf[i][j][p] = *reinterpret_cast<const u32x4*>(ptr + ((long long)((w + 8 * j) * NKC + i) * 64 + lane) * 16);
+                bf[i][j][p] = *reinterpret_cast<const u32x4*>(ptr + ((long long)(pj_tile<NTP>(w, 0, j) * NKC + i) * 64 + lane) * 16);
             }
     __syncthreads();   // the activation tile is complete
     if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8 + stamp_base + 1] = clock64();

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             if (t.r0 + row < qlen) *reinterpret_cast<f32x4*>(a.X + (long long)(t.grow0 + row) * 256 + col) = xn;
             if constexpr (NEXT != 0) {
                 static_assert(EPC == 8, "fused next projection: 16-bit operands only");
-                char* dst = smem + (col >> 6) * TILE + lds_off<128>(row, (col & 63) >> 3) + (col & 7) * 2;
+                char* dst = smem + (col >> 6) * TILE + pj_tile_off(row, (col & 63) >> 3) + (col & 7) * 2;   // the projection's own swizzle (lg_proj_body.h)
                 if constexpr (NPART == 2 && ASPLIT) {   // hi + lo planes of the new x tile (lo at G_PLANE: K-stages 0..3 of the lo g plane are just as dead)
                     uint32_t h01, l01, h23, l23;
                     split2_f16(xn[0], xn[1], h01, l01); split2_f16(xn[2], xn[3], h23, l23);

@@ -474,6 +474,12 @@ def main():
                               "frac": hbm_bytes_assign(B, n, m) / (timed["assign"][0] / timed["assign"][1] * 1e-3) / 1e9 / 8000.0,
                               "algorithmic_bytes_per_launch": hbm_bytes_assign(B, n, m),
                               "traffic": traffic_assign[0], "traffic_source": traffic_assign[1]} if "assign" in timed else None),
+            # the attention GEMMs against the same peak (north_star asks for it): algorithmic FLOPs of one self-attention launch (QK^T + PV
+            # over both images) / its average launch time from the per-class events; the split attention issues 3 MFMAs per MAC
+            "roofline_attention": ({"bound": "mfma", "kernel": "attn_self", "achieved": fl["attn_self"] / (kernel_ms["attn_self"] / L * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                                    "frac": fl["attn_self"] / (kernel_ms["attn_self"] / L * 1e-3) / 1e12 / peak, "avg_launch_ms": kernel_ms["attn_self"] / L,
+                                    "algorithmic_flops_per_launch": fl["attn_self"], "mfma_per_mac": 3 if (args.precision == "f16x3" and not args.attention) else 1,
+                                    "traffic": pmc_traffic(tkey + "attention")[0]} if "attn_self" in kernel_ms else None),
             "kernel_ms_per_step": kernel_ms,
             "kernel_ms_per_step_source": ("HIP events around every launch during the warm-up steps; the roofline kernel's entry and "
                                           "avg_launch_ms come from events inside the timed region") if warm_prof else "HIP events inside the timed region",

@@ -202,8 +202,13 @@ __global__ __launch_bounds__(GTHREADS) void gemm_kernel(GemmArgs a) {
 template <int PREC>
 __global__ __launch_bounds__(GTHREADS) void sim_kernel(SimArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int pair = blockIdx.z;
-    const int a0 = blockIdx.x * GBM, b0 = blockIdx.y * GBN;
+    // XCD-aware order: all tiles of one pair run back to back on ONE XCD, whose L2 (4 MB) then holds the pair's two projected
+    // descriptor sets (2 x n x 1 KB) for every tile that re-reads them — in the plain (x, y, pair) grid order the 8 XCDs each
+    // pulled every pair's operands from HBM (round 2: 4.6x over-fetch, profiles/r02d_pmc_fetch.md)
+    const int tx = a.rs.cap0 / GBM, ty = a.rs.cap1 / GBN;
+    const int v = xcd_remap(blockIdx.x, gridDim.x);
+    const int pair = v / (tx * ty), rem = v - pair * (tx * ty);
+    const int a0 = (rem / ty) * GBM, b0 = (rem % ty) * GBN;
     if (a0 >= a.rs.len[2 * pair] || b0 >= a.rs.len[2 * pair + 1]) return;
     const long long rowA = seg_row_base(a.rs, 2 * pair) + a0, rowB = seg_row_base(a.rs, 2 * pair + 1) + b0;
     f32x4 acc[4][4];
@@ -258,7 +263,7 @@ hipError_t launch_gemm(int prec, int epi, const GemmArgs& a, hipStream_t s) {
 }
 
 template <int PREC> static hipError_t launch_sim_prec(const SimArgs& a, hipStream_t s) {
-    dim3 grid(a.rs.cap0 / GBM, a.rs.cap1 / GBN, a.rs.B);
+    dim3 grid((a.rs.cap0 / GBM) * (a.rs.cap1 / GBN) * a.rs.B);
     auto kern = sim_kernel<PREC>;
     constexpr int smem = smem_bytes<PREC>();
     if (smem > 64 * 1024) {

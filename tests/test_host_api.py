@@ -209,3 +209,23 @@ def test_weight_changes_invalidate_the_packed_copy():
     m.refresh_weights()
     assert m._weights_sig is None
 
+
+
+def test_bench_traffic_constants_cannot_go_stale_silently(tmp_path, monkeypatch):
+    """bench.py reports PMC traffic only while profiles/pmc_traffic.json was measured on the kernel sources of this tree."""
+    import json
+
+    import bench
+    key = "f16x3/f16x3/B32/N1024/fused_tail+next"
+    rec = {"kernel_source_digest": bench.kernel_source_digest(), "bytes_per_launch": {key: 123.0}, "source": "test"}
+    f = tmp_path / "pmc_traffic.json"
+    f.write_text(json.dumps(rec))
+    monkeypatch.setattr(bench, "PMC_TRAFFIC_FILE", f)
+    assert bench.pmc_traffic(key) == (123.0, "test")
+    assert bench.pmc_traffic("no/such/key")[0] is None
+    rec["kernel_source_digest"] = "0" * 16
+    f.write_text(json.dumps(rec))
+    v, why = bench.pmc_traffic(key)
+    assert v is None and "stale" in why
+    monkeypatch.setattr(bench, "PMC_TRAFFIC_FILE", tmp_path / "missing.json")
+    assert bench.pmc_traffic(key)[0] is None

@@ -7,8 +7,8 @@
 //               ascending index order, which is what `torch.where` gives the reference).
 // adapt_compact rewrites, IN PLACE, the descriptor rows, the rotary tables and the index set of
 //               every pruned segment so that later layers see contiguous rows [0, len).
-//               In-place is safe because dst <= src: rows are processed in ascending chunks, each
-//               chunk is fully read into registers before a barrier and written after it.
+//               In-place is safe because dst <= src: rows are processed in ascending chunks (1024 rows),
+//               each chunk is fully read into registers before a barrier and written after it.
 //               Parallelism = segments x 11 column slices (8 x 128 B of the descriptor row,
 //               cos, sin, index set).
 // Per-pair state (len, active, final_layer) lives in device memory; every later kernel reads it,
@@ -112,10 +112,14 @@ __global__ __launch_bounds__(256) void adapt_compact_kernel(AdaptArgs a) {
     if (slice < 8) { buf = a.X; ld = 256; col = slice * 32; }
     else { buf = slice == 8 ? a.cosb : a.sinb; ld = 32; col = 0; }
     const int sub = tid & 7, rr = tid >> 3;  // 8 lanes x 16 B = one 128-byte row slice; 32 rows per pass
-    for (int r0 = 0; r0 < Lold; r0 += 256) {
-        f32x4 v[8]; int d[8];
+    // CU = passes per iteration.  The kernel is a chain of (read chunk | barrier | write chunk) steps per segment, i.e. bound by the
+    // number of HBM round trips, not by bytes: 8 passes (256 rows) per step ran at 0.9 TB/s in the cfg #3 trace (2048-row segments = 8
+    // dependent steps); 32 passes (1024 rows, 128 data VGPRs) make it 2 steps
+    constexpr int CU = 32;
+    for (int r0 = 0; r0 < Lold; r0 += 32 * CU) {
+        f32x4 v[CU]; int d[CU];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < CU; ++u) {
             const int r = r0 + u * 32 + rr;
             d[u] = -1;
             if (r < Lold) {
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(256) void adapt_compact_kernel(AdaptArgs a) {
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < CU; ++u) {
             const int r = r0 + u * 32 + rr;
             if (d[u] >= 0 && d[u] != r) *reinterpret_cast<f32x4*>(buf + (long long)(base + d[u]) * ld + col + sub * 4) = v[u];
         }

@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--repeat", "--r", type=int, default=100)
     ap.add_argument("--num_keypoints", nargs="+", type=int, default=[256, 512, 1024, 2048, 4096])
     ap.add_argument("--batch", type=int, default=1, help="image pairs per forward (extension; the reference benchmark is B = 1)")
-    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16x3", "bf16", "fp16", "fp32"])
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16", "fp16", "fp32"])
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("lightglue_amd needs an MI355X (ROCm device type 'cuda'); there is no CPU path to benchmark.")

@@ -20,7 +20,7 @@ from lightglue_amd import synthetic as synth  # noqa: E402
 
 def main():
     out = {"stages": {}, "golden": {}}
-    precisions = sys.argv[1:] or ["fp32", "f16x3", "bf16", "fp16"]
+    precisions = sys.argv[1:] or ["fp32", "f16x3", "f16x3/fp16", "bf16", "fp16"]
     sd = synth.make_state_dict(0, recipe="A")
     data = synth.make_batch(7, 2, 200, 160)
     for prec in precisions:

@@ -810,6 +810,14 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 ta.gamma = (blk ? e->ln_c_g : e->ln_s_g) + (size_t)i * 512; ta.beta = (blk ? e->ln_c_b : e->ln_s_b) + (size_t)i * 512;
                 ta.W2 = (blk ? e->w_ctail_2 : e->w_stail_2) + (size_t)i * e->tail_2_layer_bytes;
                 ta.b2 = (blk ? e->b_cf2 : e->b_sf2) + (size_t)i * D;
+                if (blk == 1 && i + 1 < L) {   // token confidence / matchability of layer i on the rows this CrossBlock tail produces (ref :548, :553)
+                    const bool prune_here = do_prune && prune_possible;
+                    if (do_stop) { ta.head_w0 = e->w_tok + (size_t)i * D; ta.head_b0 = e->b_tok + i; ta.head_out0 = e->CONF; }
+                    if (prune_here) {
+                        if (do_stop) { ta.head_w1 = e->w_match + (size_t)i * D; ta.head_b1 = e->b_match + i; ta.head_out1 = e->MSCORE; }
+                        else { ta.head_w0 = e->w_match + (size_t)i * D; ta.head_b0 = e->b_match + i; ta.head_out0 = e->MSCORE; }
+                    }
+                }
                 ta.dbg = e->tail_timing == 1 ? e->TAILDBG : nullptr;
                 ta.row_tiles = e->tail_row_tiles ? e->tail_row_tiles : tail_row_tiles_for(R);
                 // Across a layer boundary the fusion is valid whenever no row can MOVE in between: early stop alone only
@@ -860,19 +868,21 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
         if (i == L - 1) break;  // ref :544-545
         const bool prune_now = do_prune && prune_possible;   // below the threshold the pruning branch is never taken (ref :551 / :559)
         if (do_stop || prune_now) {
-            RowDotArgs rd{};
-            rd.rs = rs_act; rd.X = e->X;
-            if (do_stop && prune_now) {
-                rd.w0 = e->w_tok + (size_t)i * D; rd.b0 = e->b_tok + i; rd.out0 = e->CONF; rd.act0 = 1;
-                rd.w1 = e->w_match + (size_t)i * D; rd.b1 = e->b_match + i; rd.out1 = e->MSCORE; rd.act1 = 1;
-            } else if (do_stop) {
-                rd.w0 = e->w_tok + (size_t)i * D; rd.b0 = e->b_tok + i; rd.out0 = e->CONF; rd.act0 = 1;
-            } else {
-                rd.w0 = e->w_match + (size_t)i * D; rd.b0 = e->b_match + i; rd.out0 = e->MSCORE; rd.act0 = 1;
+            if (!e->fused_tail) {   // per-op path: the 256 -> 1 heads as their own pass (the fused CrossBlock tail computes them in its epilogue)
+                RowDotArgs rd{};
+                rd.rs = rs_act; rd.X = e->X;
+                if (do_stop && prune_now) {
+                    rd.w0 = e->w_tok + (size_t)i * D; rd.b0 = e->b_tok + i; rd.out0 = e->CONF; rd.act0 = 1;
+                    rd.w1 = e->w_match + (size_t)i * D; rd.b1 = e->b_match + i; rd.out1 = e->MSCORE; rd.act1 = 1;
+                } else if (do_stop) {
+                    rd.w0 = e->w_tok + (size_t)i * D; rd.b0 = e->b_tok + i; rd.out0 = e->CONF; rd.act0 = 1;
+                } else {
+                    rd.w0 = e->w_match + (size_t)i * D; rd.b0 = e->b_match + i; rd.out0 = e->MSCORE; rd.act0 = 1;
+                }
+                TRY(prof_begin(e, PC_ROWDOT, s));
+                HIPCHK(launch_rowdot(rd, s));
+                TRY(prof_end(e, s));
             }
-            TRY(prof_begin(e, PC_ROWDOT, s));
-            HIPCHK(launch_rowdot(rd, s));
-            TRY(prof_end(e, s));
             AdaptArgs ad{};
             ad.rs = rs_act; ad.len = e->LEN; ad.active = e->ACTIVE; ad.len_old = e->LEN_OLD; ad.final_layer = e->FINAL_LAYER;
             ad.ind = e->IND; ad.dst = e->DST; ad.prune0 = io->prune0; ad.prune1 = io->prune1; ad.n0 = n0; ad.n1 = n1; ad.len_orig = e->LEN_ORIG;

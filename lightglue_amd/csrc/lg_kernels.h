@@ -63,6 +63,11 @@ struct TailArgs {
     const void* W2; const float* b2;         // [256][512] fragment-packed, [256]
     long long* dbg;                          // profiling tap: [blocks][8 waves][8] shader-clock stamps, or nullptr
     int row_tiles;                           // 16-row tiles per workgroup: 4 (default; 0 = 4), 2 or 1 for under-filled grids (16-bit modes)
+    // optional 256 -> 1 heads on the NEW x rows, sigmoid applied (token confidence ref :89-94, matchability ref :298-299): up to two
+    // weight vectors [256] + bias [1] -> out [R]; nullptr = off.  Replaces a rowdot launch (and its re-read of X) per layer in the
+    // adaptive path; the dot products are reduced in a fixed order (lane values, the 4 lane groups, the 8 waves).
+    const float* head_w0; const float* head_b0; float* head_out0;
+    const float* head_w1; const float* head_b1; float* head_out1;
     // optional: the NEXT block's q/k/v projection, run on the x tile this kernel has just produced (next.W == nullptr:
     // none).  next.X is unused; supported for 16-bit operand / attention precisions (launch_tail_supports_next).
     ProjArgs next;

@@ -369,6 +369,19 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     // ended step 2, so nobody reads those stages any more (step 3 reads stages 6, 7) — no barrier needed here.
     // (loads before the first store: the compiler must assume that x aliases b2, see lg_proj_body.h)
     const f32x4 b2v[2] = {*reinterpret_cast<const f32x4*>(a.b2 + w * 32 + 4 * g), *reinterpret_cast<const f32x4*>(a.b2 + w * 32 + 16 + 4 * g)};
+    // optional heads on the new x rows (token confidence / matchability): this lane's 8 columns of each weight vector
+    const bool heads = a.head_w0 != nullptr;                         // workgroup-uniform
+    f32x4 hw0[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, hw1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (heads) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            hw0[nt] = *reinterpret_cast<const f32x4*>(a.head_w0 + w * 32 + nt * 16 + 4 * g);
+            if (a.head_w1) hw1[nt] = *reinterpret_cast<const f32x4*>(a.head_w1 + w * 32 + nt * 16 + 4 * g);
+        }
+    }
+    float hp0[MT], hp1[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { hp0[mt] = 0.f; hp1[mt] = 0.f; }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int col = w * 32 + nt * 16 + 4 * g;
@@ -378,6 +391,10 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             const int row = mt * 16 + lr;
             const f32x4 xn = xres[mt][nt] + (acc2[mt][nt] + b2);
             if (t.r0 + row < qlen) *reinterpret_cast<f32x4*>(a.X + (long long)(t.grow0 + row) * 256 + col) = xn;
+            if (heads) {
+                hp0[mt] += (xn[0] * hw0[nt][0] + xn[1] * hw0[nt][1]) + (xn[2] * hw0[nt][2] + xn[3] * hw0[nt][3]);
+                hp1[mt] += (xn[0] * hw1[nt][0] + xn[1] * hw1[nt][1]) + (xn[2] * hw1[nt][2] + xn[3] * hw1[nt][3]);
+            }
             if constexpr (NEXT != 0) {
                 static_assert(EPC == 8, "fused next projection: 16-bit operands only");
                 char* dst = smem + (col >> 6) * TILE + pj_tile_off(row, (col & 63) >> 3) + (col & 7) * 2;   // the projection's own swizzle (lg_proj_body.h)
@@ -391,6 +408,25 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
                 } else {
                     *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<Tag>(xn[0], xn[1]), pack2<Tag>(xn[2], xn[3])};
                 }
+            }
+        }
+    }
+    if (heads) {   // reduce over the 4 lane groups (the other column quarters of this wave), then over the 8 waves through LDS, in a fixed order
+        f32x2* red2 = reinterpret_cast<f32x2*>(red);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float s0 = xor32_sum(xor16_sum(hp0[mt])), s1 = xor32_sum(xor16_sum(hp1[mt]));
+            if (g == 0) red2[(mt * 16 + lr) * 8 + w] = f32x2{s0, s1};
+        }
+        __syncthreads();
+        if (tid < TBM && t.r0 + tid < qlen) {
+            const f32x4* pr = reinterpret_cast<const f32x4*>(red2 + tid * 8);
+            const f32x4 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
+            const float z0 = (((p0[0] + p0[2]) + (p1[0] + p1[2])) + ((p2[0] + p2[2]) + (p3[0] + p3[2]))) + a.head_b0[0];
+            a.head_out0[t.grow0 + tid] = 1.f / (1.f + expf(-z0));
+            if (a.head_w1) {
+                const float z1 = (((p0[1] + p0[3]) + (p1[1] + p1[3])) + ((p2[1] + p2[3]) + (p3[1] + p3[3]))) + a.head_b1[0];
+                a.head_out1[t.grow0 + tid] = 1.f / (1.f + expf(-z1));
             }
         }
     }

@@ -76,7 +76,7 @@ inline float f16_to_f32(uint16_t h) {
 
 struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
 
-// A device weight matrix [rows][K] in operand precision (+ lo half for split bf16)
+// A device weight matrix [rows][K] in operand precision (+ the lo f16 plane for PREC_F16X3)
 struct PackedW { void* hi = nullptr; void* lo = nullptr; };
 
 struct DevArena {

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Error of ONE 512-long product under the operand schemes discussed in DESIGN.md §1 / §7.1 (numpy emulation, no GPU), relative to
-sum |x||w| per output: split-bf16 x3 (the default), f16 hi planes with exact / fp6 / fp8 cross terms, one and two f16 products.
+sum |x||w| per output: split-bf16 x3 (the round 1-2 default), f16 hi planes with exact / fp6 / fp8 cross terms, one and two f16 products.
 usage: tools/study_product_error.py"""
 import sys
 from pathlib import Path
@@ -33,7 +33,7 @@ def rep(name, y):
 
 xh, wh = O.round_bf16(x), O.round_bf16(w)
 xl, wl = O.round_bf16(x - xh), O.round_bf16(w - wh)
-rep("split-bf16, 3 products (default)", f(xh) @ f(wh) + f(xh) @ f(wl) + f(xl) @ f(wh))
+rep("split-bf16, 3 products (round 1-2 default)", f(xh) @ f(wh) + f(xh) @ f(wl) + f(xl) @ f(wh))
 xh, wh = O.round_fp16(x), O.round_fp16(w)
 xl, wl = f(x) - f(xh), f(w) - f(wh)
 rep("f16 hi planes + exact cross terms", f(xh) @ f(wh) + f(xh) @ wl + xl @ f(wh))

@@ -152,7 +152,7 @@ def _port_over_reference(n, threads):
     return row["N=512" if n <= 768 else "N=1024"]
 
 
-def cpu_baseline(sd, n, m, gpu_out=None, budget_s=12.0, max_pairs=8):
+def cpu_baseline(sd, n, m, gpu_out=None, budget_s=12.0, max_pairs=8, recipe="A"):
     """CPU leg (rank 0, N = 1 only; ~20-30 s in total).  The numpy port of the reference's CPU fp32 path (oracle/) is timed on
     pairs of the SAME seeded batch the GPU matched (pair seeds 1, 2, ...), so the same calls also CHECK the GPU result
     (returned as the second value).  When /root/reference is mounted (build container) the real reference is timed beside it;
@@ -176,7 +176,7 @@ def cpu_baseline(sd, n, m, gpu_out=None, budget_s=12.0, max_pairs=8):
     refs = []
     with threadpool_limits(limits=best):
         while done < max_pairs:
-            data = synthetic.make_batch(1 + done, 1, n, m)      # == pair `done` of rank 0's GPU batch
+            data = synthetic.make_batch(1 + done, 1, n, m, **batch_kwargs(recipe))      # == pair `done` of rank 0's GPU batch
             refs.append(timed_port_forward(sd, conf, data, best))
             done += 1
             if time.perf_counter() - t0 > budget_s:
@@ -237,15 +237,21 @@ def parity_block(gpu_out, refs, n, m, source, tol=1e-3, filter_threshold=0.1):
             "max_dscore": maxd, "score_tolerance": tol, "source": source}
 
 
-def golden_parity(gpu_out, n, B):
-    """The first 4 pairs of the default workload ARE the fixture tests/golden/nonadaptive_1024_b4.npz produced by the real
-    reference (tools/make_golden.py: weights seed 0 recipe A, pair seeds 1..4)."""
-    path = ROOT / "tests" / "golden" / "nonadaptive_1024_b4.npz"
-    if n != 1024 or B < 4 or not path.exists():
+def batch_kwargs(recipe):
+    """make_batch keywords of a recipe: "D" = trained-model statistics (descriptor norms in [0.5, 3], noisier copies)."""
+    return dict(synthetic.RECIPE_D_DATA) if recipe == "D" else {}
+
+
+def golden_parity(gpu_out, n, B, recipe="A"):
+    """The first pairs of the workload ARE a fixture produced by the real reference (tools/make_golden.py, weights seed 0, pair
+    seeds 1, 2, ...): recipe A -> nonadaptive_1024_b4 (4 pairs), recipe D -> trained_stats_1024_b8 (8 pairs)."""
+    name, pairs = ("trained_stats_1024_b8", 8) if recipe == "D" else ("nonadaptive_1024_b4", 4)
+    path = ROOT / "tests" / "golden" / f"{name}.npz"
+    if n != 1024 or B < pairs or not path.exists():
         return None
     z = np.load(path, allow_pickle=False)
-    refs = [{k: z[k][b] for k in ("matches0", "matches1", "matching_scores0", "matching_scores1")} for b in range(4)]
-    return parity_block(gpu_out, refs, n, n, source="tests/golden/nonadaptive_1024_b4.npz (real reference, CPU fp32) = pairs 0..3 of the timed batch")
+    refs = [{k: z[k][b] for k in ("matches0", "matches1", "matching_scores0", "matching_scores1")} for b in range(pairs)]
+    return parity_block(gpu_out, refs, n, n, source=f"tests/golden/{name}.npz (real reference, CPU fp32) = pairs 0..{pairs - 1} of the timed batch")
 
 
 def main():
@@ -257,6 +263,8 @@ def main():
     ap.add_argument("--attention", default=None, choices=["fp16"], help="with --precision f16x3: the single-plane f16 attention (fast opt-in, outside the bar for sharp attention)")
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per step")
     ap.add_argument("--kpts", type=int, default=N_KPTS)
+    ap.add_argument("--recipe", default="A", choices=["A", "D"], help="seeded weights / inputs: A (SURVEY 8c, the headline) or D (trained-model "
+                    "statistics: attention logit spread 25, LayerNorm gains in [0.5, 4], residual rms ~27, descriptor norms in [0.5, 3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one GPU: synchronous forward per step (no deferred output assembly)")
     ap.add_argument("--no-calibration", action="store_true", help="skip the 25 ms dense-MFMA spin that measures what the box sustains (profiling runs)")
@@ -285,10 +293,10 @@ def main():
 
     n = m = args.kpts
     B = args.pairs
-    sd = synthetic.make_state_dict(0, recipe="A")
+    sd = synthetic.make_state_dict(0, recipe=args.recipe)
     model = LightGlue(features=None, depth_confidence=-1, width_confidence=-1, precision=args.precision, attention_precision=args.attention).eval()
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
-    data_np = synthetic.make_batch(1 + rank * B, B, n, m)
+    data_np = synthetic.make_batch(1 + rank * B, B, n, m, **batch_kwargs(args.recipe))
     data = {k: {kk: torch.from_numpy(vv).to(dev) for kk, vv in v.items()} for k, v in data_np.items()}
     model.reserve(B, n, m, dev)
     for kv in os.environ.get("LG_BENCH_OPTS", "").split():   # A/B of engine options (tools/ab_opt.sh), e.g. "tail_rows=64"
@@ -453,7 +461,7 @@ def main():
             "dtype": {"f16x3": "f16", "bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"SuperPoint-dim 256-d descriptors, N=M={n}, 9 layers, pruning/early-stop OFF, batch={B} pairs per GPU, "
-                                   f"seeded random weights (recipe A), precision={args.precision}"
+                                   f"seeded random weights (recipe {args.recipe}{', trained-model statistics' if args.recipe == 'D' else ''}), precision={args.precision}"
                                    + (" (split-f16 operands, 3 MFMAs per product, for every contraction incl. q k^T and P V; fp32 accumulate / residual / softmax)" if args.precision == "f16x3" and not args.attention else "")
                                    + (", attention_precision=fp16 (single-plane f16 attention: the fast opt-in, outside the 1e-3 bar for sharp attention)" if args.attention else ""),
                        "pairs_per_gpu": B, "keypoints": n, "parallelism": f"pair-sharded dp{world}",
@@ -495,9 +503,9 @@ def main():
         # match-index parity of the batch that was just timed (rank 0's pairs): against the reference's own fixture for the
         # first 4 pairs and against the oracle on the pairs the CPU leg runs anyway
         default_weights = args.precision in ("f16x3", "fp32")
-        res["parity"] = golden_parity(out, n, B) if default_weights else None
+        res["parity"] = golden_parity(out, n, B, args.recipe) if default_weights else None
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"], res["parity_oracle"] = cpu_baseline(sd, n, m, gpu_out=out)
+            res["cpu_baseline"], res["parity_oracle"] = cpu_baseline(sd, n, m, gpu_out=out, recipe=args.recipe)
         print(json.dumps(res))
     if world > 1:
         import torch.distributed as dist

@@ -412,9 +412,9 @@ def test_attention_rows_per_wave_variants_are_equivalent(precision):
     attention has the 32- and 16-row shapes; 64 maps to 32 there.)"""
     require_gpu()
     for (n0, n1, recipe, kw) in ((300, 333, "A", dict(depth_confidence=-1, width_confidence=-1)), (130, 520, "B", dict(pruning_min_kpts=64)),
-                                 (1024, 1024, "A", dict(depth_confidence=-1, width_confidence=-1))):
+                                 (1024, 1024, "A", dict(depth_confidence=-1, width_confidence=-1)), (700, 900, "D", dict(depth_confidence=-1, width_confidence=-1))):
         sd = synth.make_state_dict(0, recipe=recipe)
-        data = gpu_util.to_torch(synth.make_batch(23, 2, n0, n1))
+        data = gpu_util.to_torch(synth.make_batch(23, 2, n0, n1, **(synth.RECIPE_D_DATA if recipe == "D" else {})))
         model = gpu_util.make_model(sd, precision, **kw)
         base = model(data)
         for rows in (64, 16):
@@ -458,10 +458,11 @@ def test_tail_row_tile_shapes_are_bit_identical(precision):
     every output must be BIT-identical across shapes — fused next projection included; ragged, adaptive and batched cases."""
     require_gpu()
     for (b, n0, n1, recipe, kw) in ((3, 300, 333, "A", dict(depth_confidence=-1, width_confidence=-1)), (2, 130, 520, "B", dict(pruning_min_kpts=64)),
-                                    (1, 1024, 1024, "A", dict(depth_confidence=-1, width_confidence=-1)), (2, 40, 700, "C", dict())):
+                                    (1, 1024, 1024, "A", dict(depth_confidence=-1, width_confidence=-1)), (2, 40, 700, "C", dict()),
+                                    (2, 640, 512, "D", dict(depth_confidence=-1, width_confidence=-1))):
         sd = synth.make_state_dict(0, recipe=recipe)
         model = gpu_util.make_model(sd, precision, **kw)
-        data = gpu_util.to_torch(synth.make_batch(31, b, n0, n1))
+        data = gpu_util.to_torch(synth.make_batch(31, b, n0, n1, **(synth.RECIPE_D_DATA if recipe == "D" else {})))
         outs = {}
         for shape in (4, 2, 1, 0):
             model.set_option("tail_row_tiles", shape)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # ONE gpurun call: the profile set of a round.  Everything lands in gpurun_out/round/ (copy what is to be judged into profiles/).
-#   GPU tests + smoke, bench (default and fast opt-in), 2-rank flow test, kernel traces (cfg #2, cfg #4 shard, adaptive cfg #3', B = 1),
+#   GPU tests + smoke, bench (default, fast opt-in, recipe D), 2-rank flow test, kernel traces (cfg #2, cfg #4 shard, adaptive cfg #3', B = 1),
 #   PMC passes (SQ / FETCH_SIZE / WRITE_SIZE in their own runs, kernel trace only) for cfg #2 and for the adaptive case, all BASELINE
 #   configs on one GPU, B = 1 latency, SuperPoint extractor
 O=gpurun_out/round; mkdir -p $O
@@ -9,9 +9,10 @@ python -m pytest tests -m gpu -q > $O/gputests.log 2>&1; grep -E 'passed|failed|
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err
 python bench.py --attention fp16 --no-cpu-baseline > $O/bench_fast_attention.json 2>> $O/bench.err
+python bench.py --recipe D > $O/bench_recipe_d.json 2>> $O/bench.err    # the same workload on trained-model statistics (parity: tests/golden/trained_stats_1024_b8)
 python - <<'PY'
 import json
-for f in ("bench.json", "bench_fast_attention.json"):
+for f in ("bench.json", "bench_fast_attention.json", "bench_recipe_d.json"):
     d = json.loads(open("gpurun_out/round/" + f).read().strip().splitlines()[-1])
     print(f, round(d["value"]), round(d["ms_per_step"], 3), "sync", d["value_synchronous_forward"], "tail frac", round(d["roofline"]["frac"], 4), "attn frac", round(d["roofline_attention"]["frac"], 4),
           "hbm frac", round(d["roofline_hbm"]["frac"], 3), "cpu", (d.get("cpu_baseline") or {}).get("value"), (d.get("cpu_baseline") or {}).get("reference_estimate_pairs_per_s"), d["kernel_ms_per_step"])

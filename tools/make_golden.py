@@ -68,6 +68,12 @@ CASES = {
     # (default filter threshold: at threshold 0 this asymmetric pair has mutual-nearest-neighbour ties among scores of 1e-12, which
     # even the exact-fp32 GPU mode resolves differently from torch's summation order — 3 of 1500 — a property of the fixture, not a signal)
     "trained_stats_1500x700_w2": dict(recipe="D", data="D", wseed=2, dseed=661, B=1, n=1500, m=700, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1)),
+    # the bench workload's shape: pairs 0..7 of `bench.py --recipe D` (pair seeds 1..8) — a batch that fills the chip, so the 64-row
+    # tail workgroups and the 128-row attention workgroups run (the single-pair cases above take the small-grid shapes)
+    "trained_stats_1024_b8": dict(recipe="D", data="D", wseed=0, dseed=1, B=8, n=1024, m=1024, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1)),
+    # 128-d descriptors through input_proj (DISK / ALIKED) and the SIFT-style scale / orientation encoding under the same statistics
+    "trained_stats_disk128_1024x800": dict(recipe="D", data="D", wseed=3, dseed=681, B=1, n=1024, m=800, dim=128, conf=dict(depth_confidence=-1, width_confidence=-1, input_dim=128)),
+    "trained_stats_sift_700x600": dict(recipe="D", data="D", wseed=4, dseed=691, B=1, n=700, m=600, dim=128, conf=dict(depth_confidence=-1, width_confidence=-1, input_dim=128, add_scale_ori=True)),
 }
 
 

@@ -40,6 +40,10 @@ CASES = {
     "stop_only_600": dict(recipe="B", wseed=0, dseed=91, B=1, n=600, m=600, dim=256, prune_th=-1, conf=dict(width_confidence=-1)),
     "prune_only_600": dict(recipe="B", wseed=0, dseed=101, B=1, n=600, m=600, dim=256, prune_th=-1, conf=dict(depth_confidence=-1)),
     "empty_0x50": dict(recipe="A", wseed=0, dseed=111, B=1, n=0, m=50, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1)),
+    # fewer keypoints than one 16-row tile on either side (tile masking extremes; filter threshold 0 so that the handful of scores is compared as matches)
+    "tiny_1x17": dict(recipe="A", wseed=0, dseed=121, B=1, n=1, m=17, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1, filter_threshold=0.0)),
+    "tiny_5x3_b2": dict(recipe="A", wseed=0, dseed=131, B=2, n=5, m=3, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1, filter_threshold=0.0)),
+    "tiny_adaptive_9x30": dict(recipe="B", wseed=0, dseed=141, B=1, n=9, m=30, dim=256, prune_th=-1, conf=dict(filter_threshold=0.0)),
     # ---- BASELINE.json configs at their own shapes (round 2; VERDICT r01 "next" item 1)
     # cfg #2: the first 4 pairs of bench.py's own batch (weights seed 0 recipe A, pair seeds 1..4)
     "nonadaptive_1024_b4": dict(recipe="A", wseed=0, dseed=1, B=4, n=1024, m=1024, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1)),

@@ -445,6 +445,10 @@ def main():
             timed = {**{k: (v[0] * args.steps, v[1] * args.steps) for k, v in warm_prof.items()}, dom: timed[dom]}
         else:
             kernel_ms = {k: round(v[0] / args.steps, 4) for k, v in timed.items()}
+        # MFMAs issued per algorithmic MAC: linear layers 3 in f16x3 (the projection's x operand is one plane in the fast opt-in: its
+        # share of the tail's MACs runs 2), attention 3 with split operands, 1 otherwise
+        mfma_per_mac_attn = 3 if (args.precision == "f16x3" and not args.attention) else 1
+        mfma_per_mac_linear = (3 if not args.attention else round((3 * 393216 + 2 * 163840) / 557056, 3)) if args.precision == "f16x3" else 1
         res = {
             "metric": "image-pairs/s at N=M=1024, 9 layers; match-index parity vs ref",
             "value": value,
@@ -472,6 +476,8 @@ def main():
                          "traffic": traffic_dom[0], "traffic_source": traffic_dom[1],
                          "avg_launch_ms": dom_ms, "algorithmic_flops_per_launch": fl[dom],
                          "sustained_peak": sustained_tflops, "frac_of_sustained": (achieved / sustained_tflops if sustained_tflops else None),
+                         # matrix-core work actually ISSUED per second: the split-f16 products cost 3 MFMAs per algorithmic MAC
+                         "mfma_per_mac": mfma_per_mac_linear, "issued_tflops": achieved * mfma_per_mac_linear,
                          "note": "algorithmic FLOPs (2/MAC) of one launch / HIP-event launch duration; split f16 issues 3 MFMAs per algorithmic MAC.  "
                                  "peak = nominal dense bf16 / f16 (2.4 GHz); sustained_peak = what a dense bf16 MFMA spin "
                                  "reaches on THIS box right before the timed region (power-managed clock, see effective_mfma_clock_mhz)"},
@@ -486,7 +492,7 @@ def main():
             # over both images) / its average launch time from the per-class events; the split attention issues 3 MFMAs per MAC
             "roofline_attention": ({"bound": "mfma", "kernel": "attn_self", "achieved": fl["attn_self"] / (kernel_ms["attn_self"] / L * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                                     "frac": fl["attn_self"] / (kernel_ms["attn_self"] / L * 1e-3) / 1e12 / peak, "avg_launch_ms": kernel_ms["attn_self"] / L,
-                                    "algorithmic_flops_per_launch": fl["attn_self"], "mfma_per_mac": 3 if (args.precision == "f16x3" and not args.attention) else 1,
+                                    "algorithmic_flops_per_launch": fl["attn_self"], "mfma_per_mac": mfma_per_mac_attn, "issued_tflops": fl["attn_self"] / (kernel_ms["attn_self"] / L * 1e-3) / 1e12 * mfma_per_mac_attn,
                                     "traffic": pmc_traffic(tkey + "attention")[0]} if "attn_self" in kernel_ms else None),
             "kernel_ms_per_step": kernel_ms,
             "kernel_ms_per_step_source": ("HIP events around every launch during the warm-up steps; the roofline kernel's entry and "

@@ -209,11 +209,13 @@ __global__ __launch_bounds__(ATHREADS) void attn_kernel(AttnArgs a) {
         if (__any(grew)) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
-                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new[qt]);
+                // per ROW (see attn_dma_kernel): rows that did not grow keep their maximum, alpha = exp2(0) = 1 exactly
+                const float m_upd = m_new[qt] > m_run[qt] + 8.f ? m_new[qt] : m_run[qt];
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_upd);
                 l_run[qt] *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) o[dt][qt] *= alpha;
-                m_run[qt] = m_new[qt];
+                m_run[qt] = m_upd;
             }
         }
     };
@@ -474,7 +476,9 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_dma_kernel(AttnArgs a) {
         if (__any(grew)) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
-                const float shift = tile == 0 ? dmax[qt] : vmax2(dmax[qt], 0.f);
+                // per ROW: a row re-bases only on its own growth (shift 0 -> alpha = 1, s - 0: bit-exact no-ops), so a row's
+                // arithmetic does not depend on which rows share its wave — workgroup shapes and batch composition cannot show
+                const float shift = tile == 0 ? dmax[qt] : (dmax[qt] > 8.f ? dmax[qt] : 0.f);
                 const float alpha = tile == 0 ? 0.f : __builtin_amdgcn_exp2f(-shift);
                 l_run[qt] *= alpha;
 #pragma unroll
@@ -749,7 +753,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_split_kernel(AttnArgs a)
         if (__any(grew)) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
-                const float shift = tile == 0 ? dmax[qt] : vmax2(dmax[qt], 0.f);
+                // per ROW: a row re-bases only on its own growth (shift 0 -> alpha = 1, s - 0: bit-exact no-ops), so a row's
+                // arithmetic does not depend on which rows share its wave — workgroup shapes and batch composition cannot show
+                const float shift = tile == 0 ? dmax[qt] : (dmax[qt] > 8.f ? dmax[qt] : 0.f);
                 const float alpha = tile == 0 ? 0.f : __builtin_amdgcn_exp2f(-shift);
                 l_run[qt] *= alpha;
 #pragma unroll
@@ -819,7 +825,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_split_kernel(AttnArgs a)
         if (qrow < qlen) {
             float* dst = a.ctx + (t.grow0 + wave * (16 * QT) + qt * 16 + lr) * 256LL + head * 64 + g * 4;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(dst + dt * 16) = o[dt][qt] * inv;
+            for (int dt = 0; dt < 4; ++dt) st_stream(reinterpret_cast<f32x4*>(dst + dt * 16), f32x4(o[dt][qt] * inv));
         }
     }
 }

@@ -825,7 +825,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_split_kernel(AttnArgs a)
         if (qrow < qlen) {
             float* dst = a.ctx + (t.grow0 + wave * (16 * QT) + qt * 16 + lr) * 256LL + head * 64 + g * 4;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) st_stream(reinterpret_cast<f32x4*>(dst + dt * 16), f32x4(o[dt][qt] * inv));
+            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(dst + dt * 16) = o[dt][qt] * inv;
         }
     }
 }

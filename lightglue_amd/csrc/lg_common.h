@@ -135,23 +135,6 @@ __device__ __forceinline__ void lds_dma16(const void* gptr, void* lds) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(gptr) : "memory", "m0");
 }
 
-// Streaming (touched once per launch) activations: with LG_NT_ACT the loads / stores carry the non-temporal hint so they do not
-// displace the weight fragments every workgroup re-reads from L2 (experiment switch; tools/build_variant.sh)
-template <class V> __device__ __forceinline__ V ld_stream(const V* p) {
-#ifdef LG_NT_ACT
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
-template <class V> __device__ __forceinline__ void st_stream(V* p, V v) {
-#ifdef LG_NT_ACT
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
-
 // ---- row space
 struct RowSpace {
     int B;            // pairs in this forward

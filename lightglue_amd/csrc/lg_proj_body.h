@@ -187,10 +187,10 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
             if constexpr (OPART == 2) {                        // hi plane + lo plane (f16 of the residual, exact subtraction in fp32)
                 u32x4 hi, lo;
                 split8_f16<true>(v0, v1, hi, lo);
-                st_stream(reinterpret_cast<u32x4*>(dst), hi);
-                st_stream(reinterpret_cast<u32x4*>(dst + a.plane), lo);
+                *reinterpret_cast<u32x4*>(dst) = hi;
+                *reinterpret_cast<u32x4*>(dst + a.plane) = lo;
             } else if constexpr (sizeof(TA) == 2) {
-                st_stream(reinterpret_cast<u32x4*>(dst), pack8<Tag>(v0, v1));
+                *reinterpret_cast<u32x4*>(dst) = pack8<Tag>(v0, v1);
             } else {
                 *reinterpret_cast<f32x4*>(dst) = v0; *reinterpret_cast<f32x4*>(dst + 4) = v1;
             }
@@ -210,10 +210,10 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
                 if constexpr (OPART == 2) {
                     u32x4 hi, lo;
                     split8_f16<true>(v0, v1, hi, lo);
-                    st_stream(reinterpret_cast<u32x4*>(dst), hi);
-                    st_stream(reinterpret_cast<u32x4*>(dst + a.plane), lo);
+                    *reinterpret_cast<u32x4*>(dst) = hi;
+                    *reinterpret_cast<u32x4*>(dst + a.plane) = lo;
                 } else if constexpr (sizeof(TA) == 2) {
-                    st_stream(reinterpret_cast<u32x4*>(dst), pack8<Tag>(v0, v1));
+                    *reinterpret_cast<u32x4*>(dst) = pack8<Tag>(v0, v1);
                 } else {
                     *reinterpret_cast<f32x4*>(dst) = v0; *reinterpret_cast<f32x4*>(dst + 4) = v1;
                 }

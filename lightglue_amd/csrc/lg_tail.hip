@@ -157,7 +157,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
 #pragma unroll
         for (int i = 0; i < ROUNDS; ++i)
 #pragma unroll
-            for (int j = 0; j < NV; ++j) hreg[i][j] = ld_stream(reinterpret_cast<const f32x4*>(src + (i * SPR + sst) * KE + 4 * j));
+            for (int j = 0; j < NV; ++j) hreg[i][j] = *reinterpret_cast<const f32x4*>(src + (i * SPR + sst) * KE + 4 * j);
     };
     auto store_half = [&](int hf) {
         const int off = lds_off<128>(srow, sslot);
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         for (int mt = 0; mt < MT; ++mt) {
             const int row = mt * 16 + lr;
             const f32x4 xn = xres[mt][nt] + (acc2[mt][nt] + b2);
-            if (t.r0 + row < qlen) st_stream(reinterpret_cast<f32x4*>(a.X + (long long)(t.grow0 + row) * 256 + col), xn);
+            if (t.r0 + row < qlen) *reinterpret_cast<f32x4*>(a.X + (long long)(t.grow0 + row) * 256 + col) = xn;
             if (heads) {
                 hp0[mt] += (xn[0] * hw0[nt][0] + xn[1] * hw0[nt][1]) + (xn[2] * hw0[nt][2] + xn[3] * hw0[nt][3]);
                 hp1[mt] += (xn[0] * hw1[nt][0] + xn[1] * hw1[nt][1]) + (xn[2] * hw1[nt][2] + xn[3] * hw1[nt][3]);

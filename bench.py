@@ -306,7 +306,6 @@ def main():
         model.set_option("fused_next", 0, dev)
     if args.unfused:
         model.set_option("fused_tail", 0, dev)
-        model.set_option("fused_proj", 0, dev)
     sharded = PairShardedMatcher(model) if world > 1 else None
 
     pending = [None]

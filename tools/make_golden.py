@@ -78,6 +78,8 @@ CASES = {
     # 128-d descriptors through input_proj (DISK / ALIKED) and the SIFT-style scale / orientation encoding under the same statistics
     "trained_stats_disk128_1024x800": dict(recipe="D", data="D", wseed=3, dseed=681, B=1, n=1024, m=800, dim=128, conf=dict(depth_confidence=-1, width_confidence=-1, input_dim=128)),
     "trained_stats_sift_700x600": dict(recipe="D", data="D", wseed=4, dseed=691, B=1, n=700, m=600, dim=128, conf=dict(depth_confidence=-1, width_confidence=-1, input_dim=128, add_scale_ori=True)),
+    # cfg #4's shape under the same statistics: 4096 keys per softmax row
+    "trained_stats_disk128_4096": dict(recipe="D", data="D", wseed=3, dseed=701, B=1, n=4096, m=4096, dim=128, conf=dict(depth_confidence=-1, width_confidence=-1, input_dim=128)),
 }
 
 

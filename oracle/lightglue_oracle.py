@@ -150,6 +150,103 @@ class _Ctx:
             y = y + b
         return y
 
+    # the normalisation / activation passes of the path; numpy here, torch's CPU kernels in _TorchCtx
+    def softmax(self, x):
+        return _softmax(x, -1)
+
+    def log_softmax(self, x):
+        return _log_softmax(x, -1)
+
+    def layernorm(self, x, g, b):
+        return _layernorm(x, g, b)
+
+    def gelu(self, x):
+        return _gelu(x)
+
+    def sdpa(self, q, k, v):
+        """softmax(q k^T / sqrt(d)) v  (ref :127-130)"""
+        s = q.shape[-1] ** -0.5
+        sim = self.mm(q, np.swapaxes(k, -1, -2), "attn_qk") * s
+        return self.mm(self.softmax(sim), v, "attn_pv")
+
+    def scaled(self, x, s):
+        return x * s
+
+    def rotary(self, t, cos, sin):
+        return apply_rotary(t, cos, sin)
+
+
+class _TorchCtx(_Ctx):
+    """Same restatement, but every heavy pass runs on torch's CPU kernels (the library the reference itself computes with: ATen
+    matmul / softmax / layer_norm / gelu and the fused fp32 SDPA of ref :127-130) instead of numpy's single-core loops.  fp32 only,
+    no operand rounding.  Used for the timed ``cpu_baseline`` leg of bench.py (numpy's elementwise passes made the plain port
+    1.5-6.5x slower than the reference on the same cores, profiles/r03_cpu_reference.md) and pinned against the same golden
+    fixtures as the numpy form (tests/test_oracle_golden.py)."""
+
+    def __init__(self, dtype, quant):
+        assert dtype == np.float32 and quant in (None, "fp32"), "the torch-kernel backend is fp32 / unquantised only"
+        super().__init__(dtype, None)
+        import torch
+        import torch.nn.functional as F
+        self.torch, self.F = torch, F
+
+    def _t(self, a):
+        a = np.asarray(a)
+        if not a.flags.writeable or any(st < 0 for st in a.strides):
+            a = np.array(a)
+        return self.torch.from_numpy(a)
+
+    def mm(self, a, b, where="lin"):
+        with self.torch.no_grad():
+            return self.torch.matmul(self._t(a), self._t(b)).numpy()
+
+    def linear(self, x, w, b=None, where="lin"):
+        with self.torch.no_grad():
+            return self.F.linear(self._t(x), self._t(w), None if b is None else self._t(b)).numpy()
+
+    def softmax(self, x):
+        with self.torch.no_grad():   # transposed views arrive here (ref :221 makes the same contiguous copy first)
+            return self.torch.softmax(self._t(x).contiguous(), -1).numpy()
+
+    def log_softmax(self, x):
+        with self.torch.no_grad():
+            return self.torch.log_softmax(self._t(x).contiguous(), -1).numpy()
+
+    def layernorm(self, x, g, b):
+        with self.torch.no_grad():
+            return self.F.layer_norm(self._t(x), (x.shape[-1],), self._t(g), self._t(b), 1e-5).numpy()
+
+    def gelu(self, x):
+        with self.torch.no_grad():
+            return self.F.gelu(self._t(x)).numpy()
+
+    def sdpa(self, q, k, v):
+        with self.torch.no_grad():   # ref :127-130: the fused fp32 kernel, contiguous operands (:124)
+            q, k, v = (self._t(np.ascontiguousarray(t))[None] for t in (q, k, v))
+            return self.F.scaled_dot_product_attention(q, k, v)[0].numpy()
+
+    def scaled(self, x, s):
+        with self.torch.no_grad():
+            return (self._t(x) * s).numpy()
+
+    def rotary(self, t, cos, sin):
+        """ref :58-65, same pairing as apply_rotary"""
+        with self.torch.no_grad():
+            t, c, sn = self._t(t), self._t(cos), self._t(sin)
+            te, to = t[..., 0::2], t[..., 1::2]
+            out = self.torch.empty(t.shape, dtype=t.dtype)
+            out[..., 0::2] = te * c - to * sn
+            out[..., 1::2] = to * c + te * sn
+            return out.numpy()
+
+
+def make_ctx(dtype, quant, backend="numpy"):
+    if backend == "numpy":
+        return _Ctx(dtype, quant)
+    if backend == "torch":
+        return _TorchCtx(dtype, quant)
+    raise ValueError(f"unknown oracle backend {backend!r}")
+
 
 def _sigmoid(x):
     # numerically stable; matches torch.sigmoid to rounding
@@ -223,10 +320,7 @@ def attention(ctx: _Ctx, q, k, v):
     """ref :113-130 (CPU branch = fp32 SDPA, scale 1/sqrt(64)).  q [H,nq,64], k,v [H,nk,64]."""
     if q.shape[-2] == 0 or k.shape[-2] == 0:
         return np.zeros((*q.shape[:-1], v.shape[-1]), dtype=q.dtype)
-    s = q.shape[-1] ** -0.5
-    sim = ctx.mm(q, np.swapaxes(k, -1, -2), "attn_qk") * s
-    attn = _softmax(sim, -1)
-    return ctx.mm(attn, v, "attn_pv")
+    return ctx.sdpa(q, k, v)
 
 
 def _ffn(ctx: _Ctx, p: Dict[str, np.ndarray], prefix: str, x, msg, tr=None, tag=""):
@@ -234,8 +328,8 @@ def _ffn(ctx: _Ctx, p: Dict[str, np.ndarray], prefix: str, x, msg, tr=None, tag=
     h = ctx.linear(np.concatenate([x, msg], -1), p[prefix + "ffn.0.weight"], p[prefix + "ffn.0.bias"], "lin_ffn0")
     if tr is not None:
         tr[tag + "h1"] = h
-    h = _layernorm(h, p[prefix + "ffn.1.weight"], p[prefix + "ffn.1.bias"])
-    h = _gelu(h)
+    h = ctx.layernorm(h, p[prefix + "ffn.1.weight"], p[prefix + "ffn.1.bias"])
+    h = ctx.gelu(h)
     if tr is not None:
         tr[tag + "g"] = h
     return x + ctx.linear(h, p[prefix + "ffn.3.weight"], p[prefix + "ffn.3.bias"], "lin_ffn3")
@@ -248,8 +342,8 @@ def self_block(ctx: _Ctx, p, i: int, x, cos, sin, heads: int, tr=None, tag=""):
     qkv = ctx.linear(x, p[pre + "Wqkv.weight"], p[pre + "Wqkv.bias"], "lin_qkv")  # [n,768]
     qkv = qkv.reshape(n, heads, -1, 3).transpose(1, 0, 2, 3)  # unflatten(-1,(H,-1,3)).transpose(1,2)
     q, k, v = qkv[..., 0], qkv[..., 1], qkv[..., 2]  # [H,n,64]
-    q = apply_rotary(q, cos, sin)
-    k = apply_rotary(k, cos, sin)
+    q = ctx.rotary(q, cos, sin)
+    k = ctx.rotary(k, cos, sin)
     context = attention(ctx, q, k, v)  # [H,n,64]
     message = ctx.linear(context.transpose(1, 0, 2).reshape(n, -1), p[pre + "out_proj.weight"], p[pre + "out_proj.bias"], "lin_out")
     if tr is not None:
@@ -274,10 +368,10 @@ def cross_block(ctx: _Ctx, p, i: int, x0, x1, heads: int, tr=None, tag=""):
         m1 = np.zeros_like(qk1)
     else:
         scale = (qk0.shape[-1] ** -0.5) ** 0.5
-        qk0, qk1 = qk0 * scale, qk1 * scale
+        qk0, qk1 = ctx.scaled(qk0, scale), ctx.scaled(qk1, scale)
         sim = ctx.mm(qk0, np.swapaxes(qk1, -1, -2), "attn_qk")  # [H,n0,n1]
-        attn01 = _softmax(sim, -1)
-        attn10 = _softmax(np.swapaxes(sim, -1, -2), -1)  # [H,n1,n0]
+        attn01 = ctx.softmax(sim)
+        attn10 = ctx.softmax(np.swapaxes(sim, -1, -2))  # [H,n1,n0]
         m0 = ctx.mm(attn01, v1, "attn_pv")
         m1 = ctx.mm(attn10, v0, "attn_pv")
     def merge(t):
@@ -314,8 +408,8 @@ def log_assignment(ctx: _Ctx, p, i: int, x0, x1):
     z1 = matchability_logit(p, i, x1)[:, None]
     m, n = sim.shape
     certainties = _logsigmoid(z0) + _logsigmoid(z1).T
-    scores0 = _log_softmax(sim, 1)
-    scores1 = _log_softmax(sim.T, 1).T
+    scores0 = ctx.log_softmax(sim)
+    scores1 = ctx.log_softmax(sim.T).T
     scores = np.zeros((m + 1, n + 1), dtype=sim.dtype)
     scores[:m, :n] = scores0 + scores1 + certainties
     scores[:-1, -1] = _logsigmoid(-z0[:, 0])
@@ -349,12 +443,13 @@ def filter_matches(scores: np.ndarray, th: float):
 def forward_pair(params: Dict[str, np.ndarray], conf: SimpleNamespace,
                  kpts0, kpts1, desc0, desc1, size0=None, size1=None,
                  scales0=None, oris0=None, scales1=None, oris1=None,
-                 dtype=np.float32, quant: Optional[str] = None, trace: Optional[dict] = None):
+                 dtype=np.float32, quant: Optional[str] = None, trace: Optional[dict] = None, backend: str = "numpy"):
     """ref :483-629 for ONE pair (the reference's adaptive path is only defined for B=1,
     SURVEY.md §0).  Inputs: kpts [n,2] pixels, desc [n,D_in].  Returns the reference's dict
     with the batch dimension dropped.  ``trace`` (optional dict) receives per-layer
-    descriptors for localising a mismatch."""
-    ctx = _Ctx(dtype, quant)
+    descriptors for localising a mismatch.  ``backend``: "numpy" (the checker) or "torch" (the same restatement on torch's CPU
+    kernels, fp32 only: the timed cpu_baseline leg)."""
+    ctx = make_ctx(dtype, quant, backend)
     p = {k: np.asarray(v, dtype=dtype) for k, v in params.items()}
     L, H = conf.n_layers, conf.num_heads
     thr = confidence_thresholds_f32(L).astype(dtype)
@@ -465,7 +560,7 @@ def forward_pair(params: Dict[str, np.ndarray], conf: SimpleNamespace,
     }
 
 
-def forward(params, conf, data: dict, dtype=np.float32, quant=None):
+def forward(params, conf, data: dict, dtype=np.float32, quant=None, backend: str = "numpy"):
     """Batched wrapper: a Python loop of B=1 calls (every pair prunes/stops
     independently).  data = {"image0": {"keypoints" [B,N,2], "descriptors" [B,N,D],
     optional "image_size" [B,2], "scales","oris" [B,N]}, "image1": {...}}.
@@ -483,7 +578,7 @@ def forward(params, conf, data: dict, dtype=np.float32, quant=None):
         outs.append(forward_pair(
             params, conf, g(d0, "keypoints"), g(d1, "keypoints"), g(d0, "descriptors"), g(d1, "descriptors"),
             g(d0, "image_size"), g(d1, "image_size"), g(d0, "scales"), g(d0, "oris"), g(d1, "scales"), g(d1, "oris"),
-            dtype=dtype, quant=quant))
+            dtype=dtype, quant=quant, backend=backend))
     res = {k: np.stack([o[k] for o in outs]) for k in
            ("matches0", "matches1", "matching_scores0", "matching_scores1", "prune0", "prune1")}
     res["stop"] = [o["stop"] for o in outs]

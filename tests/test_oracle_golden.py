@@ -29,6 +29,26 @@ def test_oracle_matches_reference_golden(name):
         np.testing.assert_array_equal(ml[:, 1], out["matches0"][b][ml[:, 0]])
 
 
+# the torch-kernel backend of the oracle (the timed cpu_baseline leg of bench.py) is pinned against the same fixtures: small / edge cases,
+# both adaptive paths, trained statistics, 128-d and scale/orientation inputs, and the bench batch's own fixture
+TORCH_BACKEND_CASES = [n for n in golden_names() if any(t in n for t in ("bbox_300x200", "empty", "1x17", "5x3", "adaptive_9x30", "adaptive_1024",
+                                                                          "trained_stats_512", "sift", "disk128_256", "mutualnn", "nonadaptive_1024_b4"))]
+
+
+@pytest.mark.parametrize("name", TORCH_BACKEND_CASES)
+def test_torch_backend_matches_reference_golden(name):
+    meta, gold = load_golden(name)
+    sd, data = make_golden.case_inputs(meta["case"])
+    out = O.forward(sd, oracle_conf_for(meta["case"]), data, backend="torch")
+    np.testing.assert_array_equal(out["matches0"], gold["matches0"])
+    np.testing.assert_array_equal(out["matches1"], gold["matches1"])
+    np.testing.assert_allclose(out["matching_scores0"], gold["matching_scores0"], atol=2e-4, rtol=0)
+    np.testing.assert_allclose(out["matching_scores1"], gold["matching_scores1"], atol=2e-4, rtol=0)
+    assert out["stop"] == gold["stop"].tolist()
+    np.testing.assert_array_equal(np.asarray(out["prune0"], np.float32), gold["prune0"])
+    np.testing.assert_array_equal(np.asarray(out["prune1"], np.float32), gold["prune1"])
+
+
 @pytest.mark.skipif(not make_golden.REF.exists(), reason="reference tree not mounted")
 def test_oracle_live_against_reference():
     lg = make_golden.load_reference()

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Time the UNMODIFIED reference (CPU fp32, B = 1, pruning / early stop off) and the numpy port (oracle/) side by side in the
-build container, at N = M = 512 and 1024 with 1 and 8 threads -> profiles/r03_cpu_reference.md.  The ratios feed
-bench.py's PORT_OVER_REFERENCE_TIME (the GPU box has no /root/reference, so bench.py times the port there and reports
-`reference_estimate_pairs_per_s = value x ratio` next to it).   usage: python tools/cpu_reference_table.py > profiles/r03_cpu_reference.md"""
+"""Time the UNMODIFIED reference (CPU fp32, B = 1, pruning / early stop off) and the two forms of the port (oracle/: numpy = the
+checker, torch-kernel backend = bench.py's timed cpu_baseline leg) side by side in the build container, at N = M = 512 and 1024 with
+1 and 8 threads -> profiles/r03_cpu_reference.md.  The torch-backend ratios feed bench.py's PORT_OVER_REFERENCE_TIME (the GPU box has
+no /root/reference, so bench.py times the port there and reports `reference_estimate_pairs_per_s = value x ratio` next to it).
+usage: python tools/cpu_reference_table.py > profiles/r03_cpu_reference.md"""
 import os
 import sys
 import time
@@ -17,16 +18,19 @@ from threadpoolctl import threadpool_limits  # noqa: E402
 
 sd = synthetic.make_state_dict(0, recipe="A")
 conf = O.make_conf(depth_confidence=-1, width_confidence=-1)
-print(f"# r03 — reference CPU path vs the numpy port, build container ({bench._cpu_model()}, {os.cpu_count()} logical cores)\n")
+import torch  # noqa: E402
+
+print(f"# r03 — reference CPU path vs the port (oracle/), build container ({bench._cpu_model()}, {os.cpu_count()} logical cores)\n")
 print("`tools/cpu_reference_table.py`: unmodified `/root/reference/lightglue/lightglue.py` loaded standalone, CPU fp32, B = 1, recipe-A weights,")
-print("pruning / early stop off, 2 warm-up + 5 timed forwards; port = `oracle/lightglue_oracle.py` (`bench.py`'s timed CPU leg) under")
-print("`threadpool_limits`.\n")
-print("| N = M | threads | reference ms | reference pairs/s | port ms | port pairs/s | port / reference time |")
-print("|---|---|---|---|---|---|---|")
+print("pruning / early stop off, 2 warm-up + 5 timed forwards (best of 2 passes); port = `oracle/lightglue_oracle.py`: `numpy` = the checker")
+print("(numpy / OpenBLAS under `threadpool_limits`), `torch` = the same restatement on torch's CPU kernels (`backend=\"torch\"`, `bench.py`'s")
+print("timed cpu_baseline leg, `torch.set_num_threads`).\n")
+print("| N = M | threads | reference ms | reference pairs/s | numpy port ms | numpy / reference time | torch-backend port ms | torch-backend pairs/s | torch-backend / reference time |")
+print("|---|---|---|---|---|---|---|---|---|")
 ratios = {}
 for n in (512, 1024):
     for th in (1, 8):
-        tr = bench._time_reference(sd, n, th, reps=5)
+        tr = min(bench._time_reference(sd, n, th, reps=5) for _ in range(2))
         data = synthetic.make_batch(1, 1, n, n)
         with threadpool_limits(limits=th):
             O.forward(sd, conf, data)
@@ -34,6 +38,15 @@ for n in (512, 1024):
             for _ in range(3):
                 O.forward(sd, conf, data)
             tp = (time.perf_counter() - t0) / 3
-        ratios[(n, th)] = tp / tr
-        print(f"| {n} | {th} | {tr * 1e3:.1f} | {1 / tr:.2f} | {tp * 1e3:.1f} | {1 / tp:.2f} | {tp / tr:.2f} |", flush=True)
+        old = torch.get_num_threads(); torch.set_num_threads(th)
+        tt = float("inf")
+        for _ in range(2):
+            O.forward(sd, conf, data, backend="torch")
+            t0 = time.perf_counter()
+            for _ in range(5):
+                O.forward(sd, conf, data, backend="torch")
+            tt = min(tt, (time.perf_counter() - t0) / 5)
+        torch.set_num_threads(old)
+        ratios[(n, th)] = tt / tr
+        print(f"| {n} | {th} | {tr * 1e3:.1f} | {1 / tr:.2f} | {tp * 1e3:.1f} | {tp / tr:.2f} | {tt * 1e3:.1f} | {1 / tt:.2f} | {tt / tr:.2f} |", flush=True)
 print("\nPORT_OVER_REFERENCE_TIME =", {f"{th} thread{'s' if th > 1 else ''}": {f"N={n}": round(ratios[(n, th)], 2) for n in (512, 1024)} for th in (1, 8)})

@@ -154,3 +154,36 @@ def test_errors_on_gpu_inputs():
         model({"image0": d, "image1": d})       # wrong descriptor dim (ref :505-506)
     with pytest.raises(AssertionError):
         model({"image0": d})                    # missing key (ref :484-485)
+
+
+def test_repeated_forwards_are_bit_identical_under_workspace_churn():
+    """Race / stale-state soak: the same adaptive batch (early stop + in-place pruning compaction, recipe B: progressive pruning at
+    every layer) and the same non-adaptive batch, 12 forwards each, interleaved with forwards of OTHER shapes through the same engine
+    (which re-use, and for the larger one re-allocate, the workspace) and with the pipelined `forward_deferred` form: every output
+    tensor must come back bit for bit."""
+    require_gpu()
+    n = 1024
+    # depth_confidence 0.999: all 9 layers run and the oracle prunes at 7 of them (prune0 histogram 129 / 151 / 5 / 191 / 38 / 43 / 1 / 466)
+    adaptive = gpu_util.make_model(synth.make_state_dict(0, recipe="B"), "f16x3", pruning_min_kpts=256, depth_confidence=0.999)
+    plain = _model(depth_confidence=-1, width_confidence=-1)
+    da = gpu_util.to_torch(synth.make_batch(900, 3, n, 768))
+    dp = gpu_util.to_torch(synth.make_batch(910, 4, 640, 512))
+    other = [gpu_util.to_torch(synth.make_batch(920 + i, b, a, c)) for i, (b, a, c) in enumerate(((1, 200, 130), (2, 1536, 1100), (5, 300, 300)))]
+    keys = ("matches0", "matches1", "matching_scores0", "matching_scores1", "prune0", "prune1")
+
+    def snap(out):
+        return {k: out[k].clone() for k in keys} | {"stop": torch.as_tensor(out["stop"]).clone().cpu(), "n": [int(x.shape[0]) for x in out["matches"]]}
+
+    ref_a, ref_p = snap(adaptive(da)), snap(plain(dp))
+    assert len(torch.unique(ref_a["prune0"])) >= 5, "the adaptive fixture must prune at several layers"
+    for it in range(12):
+        adaptive(other[it % 3]); plain(other[(it + 1) % 3])
+        if it % 2:
+            ha, hp = adaptive.forward_deferred(da), plain.forward_deferred(dp)
+            got_a, got_p = snap(ha.result()), snap(hp.result())
+        else:
+            got_a, got_p = snap(adaptive(da)), snap(plain(dp))
+        for ref, got, tag in ((ref_a, got_a, "adaptive"), (ref_p, got_p, "plain")):
+            for k in keys:
+                assert torch.equal(ref[k], got[k]), f"{tag} forward {it}: {k} changed between identical calls"
+            assert torch.equal(ref["stop"], got["stop"]) and ref["n"] == got["n"], f"{tag} forward {it}: stop / match counts changed"

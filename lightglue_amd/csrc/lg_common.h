@@ -161,6 +161,14 @@ __device__ __forceinline__ int seg_row_base(const RowSpace& rs, int seg) {
 // ---- XCD-aware workgroup order.  The dispatcher places workgroup b on XCD b % 8 (observed, used for
 // L2 locality only — never for correctness).  Bijective for any grid size (guide §5 "XCD swizzle must
 // be bijective"): XCD x owns the virtual ids [start(x), start(x) + count(x)).
+// One-workgroup-per-CU kernels (the fused tail): with the grid a multiple of the 256 CUs, workgroup id runs in round id / 256 on CU slot
+// id % 256 (uniform workgroups, round-robin dispatch).  This map gives slot s the ADJACENT tiles s * rounds + round, so that the tile a
+// CU starts on lies next to the one it has just finished (same pages of x / ctx / q / k and the same 128-byte-strided lines of v^T) instead
+// of 256 tiles = 16 MB further on.  Round-3 A/B in one box, two rounds: tail -1.8 % / -2.9 %, whole step +0.5 % / +1.1 %
+// (profiles/r03i_tail_interleave.md).  Other grid sizes keep the identity.
+__device__ __forceinline__ int cu_slot_interleave(int id, int nwg) {
+    return (nwg & 255) == 0 ? (id & 255) * (nwg >> 8) + (id >> 8) : id;
+}
 __device__ __forceinline__ int xcd_remap(int id, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, k = id >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;

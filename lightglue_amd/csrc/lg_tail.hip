@@ -116,7 +116,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem + TL<PREC, MT>::G_BYTES);
 
-    const TileLoc t = locate_tile(a.rs, blockIdx.x, TBM);
+    const TileLoc t = locate_tile(a.rs, cu_slot_interleave(blockIdx.x, gridDim.x), TBM);
     if (t.r0 >= a.rs.len[t.seg]) return;
     if (a.rs.active && !a.rs.active[t.pair]) return;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, g = lane >> 4;

@@ -35,3 +35,4 @@ find $O -name "*.db" -delete
 timeout 400 python tools/bench_configs.py 2>&1 | grep -v amdgpu.ids | tail -13; cp gpurun_out/configs.md $O/configs.md
 timeout 200 python tools/latency_b1.py 2>&1 | grep -v amdgpu.ids > $O/latency_b1.log; cat $O/latency_b1.log
 timeout 200 python tools/bench_superpoint.py 2>&1 | grep -v amdgpu.ids | tail -8 | tee $O/superpoint.log
+( python tools/tail_timing.py f16x3 1; python tools/tail_wall.py ) 2>&1 | grep -v amdgpu.ids | tee $O/tail_timing.log

@@ -161,17 +161,6 @@ __device__ __forceinline__ int seg_row_base(const RowSpace& rs, int seg) {
 // ---- XCD-aware workgroup order.  The dispatcher places workgroup b on XCD b % 8 (observed, used for
 // L2 locality only — never for correctness).  Bijective for any grid size (guide §5 "XCD swizzle must
 // be bijective"): XCD x owns the virtual ids [start(x), start(x) + count(x)).
-// One-workgroup-per-CU kernels (the fused tail): workgroup id runs in round id / 256 on CU slot id % 256 (uniform workgroups, round-robin
-// dispatch over the 256 CUs; tools/tail_wall.py prints how often that holds).  This map gives slot s the ADJACENT tiles prefix(s) + round,
-// so that the tile a CU starts on lies next to the one it has just finished (same pages of x / ctx / q / k and the same 128-byte-strided
-// lines of v^T) instead of 256 tiles = 16 MB further on.  Round-3 A/B in one box, two rounds: tail -1.8 % / -2.9 %, whole step +0.5 % /
-// +1.1 %, HBM traffic of the tail 540 -> 505 MB per launch (profiles/r03i_tail_interleave.md).  A bijection for every grid size: with
-// `full` = nwg % 256 slots that still get a workgroup in the last round, slot s owns rounds - (full && s >= full) consecutive tiles.
-__device__ __forceinline__ int cu_slot_interleave(int id, int nwg) {
-    if (nwg <= 256) return id;
-    const int s = id & 255, k = id >> 8, rounds = (nwg + 255) >> 8, full = nwg & 255;
-    return s * rounds + k - ((full && s > full) ? s - full : 0);
-}
 __device__ __forceinline__ int xcd_remap(int id, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, k = id >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;

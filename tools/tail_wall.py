@@ -32,9 +32,11 @@ for c in u:
     gaps += list((t0[o][1:] - t1[o][:-1]) / 100.0)
 gaps = np.array(gaps)
 print("distinct CUs", len(u), " workgroups per CU min/max", min(per), max(per))
-if len(d) % 256 == 0:   # cu_slot_interleave (lg_common.h) assumes workgroup id runs on CU slot id % 256: how often is that true?
+if len(d) % 256 == 0:   # does workgroup id run on CU slot id % 256?  (no: only its XCD, id % 8, is fixed — which is what the tail's xcd_remap tile order relies on)
     ids = np.arange(len(d))
     same = sum(1 for c in u if np.unique(ids[cu == c] % 256).size == 1)
     print("CUs whose workgroups all have the same id %% 256: %d of %d" % (same, len(u)))
+    xcc = (raw[:, 0] >> 44) & 0xF
+    print("workgroups whose XCC_ID == id %% 8: %d of %d" % (int((xcc == ids % 8).sum()), len(d)))
 print("gap between consecutive workgroups on a CU, us: median %.2f p10 %.2f p90 %.2f  (negative = overlap)" % (np.median(gaps), np.percentile(gaps, 10), np.percentile(gaps, 90)))
 print("first start spread us: %.1f; last end - median end of final round %.1f" % (np.percentile((t0 - base) / 100.0, 24), (t1.max() - np.median(np.sort(t1)[-256:])) / 100.0))

@@ -158,6 +158,18 @@ __device__ __forceinline__ int seg_row_base(const RowSpace& rs, int seg) {
     return (seg >> 1) * (rs.cap0 + rs.cap1) + (seg & 1) * rs.cap0;
 }
 
+// Workgroup id runs on XCD id % 8 (round-robin dispatch; tools/tail_wall.py: 1024 of 1024).  For a kernel whose tiles share nothing (the
+// fused tail) the identity map hands XCD x every tile = x (mod 8), i.e. one fixed residue of the address bits above the 64 KB tile size,
+// for the whole launch — and when the live tiles of a ragged / pruned / partly stopped batch have a period that is a multiple of 8 tiles
+// (cfg #5: 40 tiles per pair, live ones at 0..8 and 32..36) some XCDs get 2-3x the work of others.  Rotating the residue by the group
+// index gives every XCD every residue in turn and spreads any such pattern; whole inactive pairs still cost every XCD the same (a
+// contiguous chunk per XCD, as the attention uses for K / V reuse, does not: cfg #3' -15 %).  Bijective for every grid size.
+__device__ __forceinline__ int rr_rotate(int id, int nwg) {
+    if (id >= (nwg & ~7)) return id;
+    const int q = id >> 3;
+    return (q << 3) + ((id + q) & 7);
+}
+
 // ---- XCD-aware workgroup order.  The dispatcher places workgroup b on XCD b % 8 (observed, used for
 // L2 locality only — never for correctness).  Bijective for any grid size (guide §5 "XCD swizzle must
 // be bijective"): XCD x owns the virtual ids [start(x), start(x) + count(x)).

@@ -116,11 +116,9 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem + TL<PREC, MT>::G_BYTES);
 
-    // XCD-aware tile order (workgroup id runs on XCD id % 8): every XCD takes one contiguous eighth of the row tiles, in order, so that its
-    // L2 and TLB work on one region of x / ctx / q / k / v^T per round instead of on every eighth tile of the whole batch.  Round-3 A/B
-    // (profiles/r03l_tail_tile_maps.md, one box, two rounds): identity 3790 / 3798 pairs/s, this map 3824 / 3834 (tail -1.8 %); a
-    // per-CU-slot interleave sat in between, and tools/tail_wall.py shows why: a CU does NOT keep the slot id % 256 (10 of 256 do).
-    const TileLoc t = locate_tile(a.rs, xcd_remap(blockIdx.x, gridDim.x), TBM);
+    // workgroup -> row tile: round-robin with the residue rotated per group of 8 (rr_rotate, lg_common.h).  Round-3 A/B against the identity
+    // map, one box (profiles/r03q_tail_tile_maps.md): cfg #2 +2.3 % (tail -3.7 %), cfg #3' +1.1 %, cfg #5 +4.4 % / +8.7 %.
+    const TileLoc t = locate_tile(a.rs, rr_rotate(blockIdx.x, gridDim.x), TBM);
     if (t.r0 >= a.rs.len[t.seg]) return;
     if (a.rs.active && !a.rs.active[t.pair]) return;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, g = lane >> 4;

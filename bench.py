@@ -9,6 +9,7 @@ log-assignment, match filtering and the ragged match lists).
     python bench.py [--gpus N --steps K --warmup W] [--precision f16x3|bf16|fp16|fp32] [--attention fp16]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (no launcher: bench.py spawns the same N ranks itself on a free loopback port)
 
 N > 1: one process per GPU, every rank matches its own 32 pairs (weak scaling, no data-path
 collective) and the match indices are all-gathered over RCCL each step (lightglue_amd.parallel).
@@ -284,6 +285,21 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="use the per-op kernels instead of the fused block tail")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N` (no launcher): spawn the N ranks ourselves — one process per GPU through
+        # torch.distributed.run on a free loopback port — and hand its exit code on.  Only rank 0 writes to stdout (the ONE JSON
+        # line); the launcher's own chatter goes to stderr.  Under torchrun (WORLD_SIZE set) this branch is never taken.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=env).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -311,7 +327,7 @@ def main():
     data_np = synthetic.make_batch(1 + rank * B, B, n, m, **batch_kwargs(args.recipe))
     data = {k: {kk: torch.from_numpy(vv).to(dev) for kk, vv in v.items()} for k, v in data_np.items()}
     model.reserve(B, n, m, dev)
-    for kv in os.environ.get("LG_BENCH_OPTS", "").split():   # A/B of engine options (tools/ab_opt.sh), e.g. "tail_rows=64"
+    for kv in os.environ.get("LG_BENCH_OPTS", "").split():   # A/B of engine options in one box, e.g. LG_BENCH_OPTS="tail_row_tiles=2 attn_rows=64"
         key, val = kv.split("=")
         model.set_option(key, int(val), dev)
     if args.no_fuse_next:

@@ -229,3 +229,33 @@ def test_bench_traffic_constants_cannot_go_stale_silently(tmp_path, monkeypatch)
     assert v is None and "stale" in why
     monkeypatch.setattr(bench, "PMC_TRAFFIC_FILE", tmp_path / "missing.json")
     assert bench.pmc_traffic(key)[0] is None
+
+
+def test_bench_spawns_its_own_ranks_without_a_launcher(monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment re-launches itself under torch.distributed.run with N ranks on a
+    loopback port and returns the launcher's exit code (the GPU rehearsal is tests/test_parallel_gpu.py)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import bench
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as exc:
+        bench.main()
+    assert exc.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

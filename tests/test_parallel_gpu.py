@@ -99,3 +99,24 @@ def test_two_ranks_sharing_one_gpu_equal_plain_forward(ragged):
         for k in KEYS:
             np.testing.assert_array_equal(got[rank][k], plain[k].cpu().numpy(), err_msg=f"rank {rank} {k}")
         np.testing.assert_array_equal(got[rank]["stop"], plain["stop"].cpu().numpy())
+
+
+def test_plain_bench_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` WITHOUT a launcher must spawn its two ranks itself (the driver's scaling run may
+    use the plain form).  Rehearsal on one GPU: both ranks share cuda:0 and talk over gloo; the JSON line must be the only stdout line."""
+    require_gpu()
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LG_BENCH_ONE_GPU="1", LG_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl"]["world"] == 2 and len(d["rccl"]["ranks_seen"]) == 2
+    assert d["parity"]["index_mismatches"] == 0 and d["parity"]["unexplained"] == 0

@@ -300,6 +300,12 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
         sys.exit(subprocess.run(cmd, env=env).returncode)
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints its version banner on init, gloo its
+    # "connected to N peer ranks" lines), so file descriptor 1 is pointed at stderr for the whole run and rank 0 writes the line to a
+    # private duplicate of the original stdout.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -539,7 +545,8 @@ def main():
         res["parity"] = golden_parity(out, n, B, args.recipe) if default_weights else None
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"], res["parity_oracle"] = cpu_baseline(sd, n, m, gpu_out=out, recipe=args.recipe)
-        print(json.dumps(res))
+        json_out.write(json.dumps(res) + "\n")
+        json_out.flush()
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

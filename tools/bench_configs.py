@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Time the HIP path on the five BASELINE.json configs (1 GPU).  Writes gpurun_out/configs.md."""
+"""Time the HIP path on the five BASELINE.json configs (1 GPU).  Writes gpurun_out/configs.md.
+    tools/bench_configs.py [tag ...]      only the configs whose name starts with one of the tags, e.g.  "#2 " "#3' " "#5' "
+(the library is picked by LIGHTGLUE_AMD_LIB as everywhere: a tile map or kernel variant is A/B'd on the adaptive / ragged configs too)"""
 import sys, time
 from pathlib import Path
 import numpy as np, torch
@@ -21,7 +23,10 @@ CFGS = [
     ("#5' same in f16x3 (the parity-holding mode)", dict(B=64, n=2048, m=512, dim=128, prec="f16x3", recipe="C", wseed=2, kw=dict(input_dim=128))),
 ]
 lines = ["| config | pairs/s | ms/batch | mean stop | stop histogram (layers 1..9) | mean kept pts img0 (last layer) | matches/pair |", "|---|---|---|---|---|---|---|"]
+ONLY = sys.argv[1:]
 for name, c in CFGS:
+    if ONLY and not any(name.startswith(t) for t in ONLY):
+        continue
     sd = synth.make_state_dict(c.get("wseed", 0), recipe=c["recipe"], input_dim=c["dim"])
     model = gpu_util.make_model(sd, c["prec"], **c["kw"])
     data = gpu_util.to_torch(synth.make_batch(1, c["B"], c["n"], c["m"], c["dim"]))
@@ -37,4 +42,5 @@ for name, c in CFGS:
     print(lines[-1], flush=True)
     del model
 Path(ROOT / "gpurun_out").mkdir(exist_ok=True)
-(ROOT / "gpurun_out" / "configs.md").write_text("\n".join(lines) + "\n")
+if not ONLY:
+    (ROOT / "gpurun_out" / "configs.md").write_text("\n".join(lines) + "\n")

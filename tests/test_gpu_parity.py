@@ -41,7 +41,9 @@ def test_fp32_mode_matches_golden_exactly(name):
     np.testing.assert_array_equal(out["matches1"].cpu().numpy(), gold["matches1"])
     # fp32 summation order differs from torch's; on the recipe-D fixtures (residual rms 27, sharp softmax rows) that alone moves
     # a score by up to 2.2e-4 (the numpy oracle itself: 1.4e-4) — still 4x inside the 1e-3 bar
-    atol = 5e-4 if name.startswith("trained_stats") else 2e-4
+    # On the confident-match fixtures (recipe E) the fp32 floor is wider still: the oracle's own float64 evaluation is up to 7.1e-4 from
+    # the reference (tests/test_oracle_golden.py:oracle_score_atol), so the bar itself (1e-3) is the assertion there
+    atol = SCORE_TOL if name.startswith("trained_stats_confident") else 5e-4 if name.startswith("trained_stats") else 2e-4
     np.testing.assert_allclose(out["matching_scores0"].cpu().numpy(), gold["matching_scores0"], atol=atol, rtol=0)
     np.testing.assert_allclose(out["matching_scores1"].cpu().numpy(), gold["matching_scores1"], atol=atol, rtol=0)
     stop = out["stop"] if not torch.is_tensor(out["stop"]) else out["stop"].cpu().tolist()

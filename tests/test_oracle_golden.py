@@ -9,6 +9,15 @@ from lightglue_amd import synthetic as synth
 import make_golden
 
 
+def oracle_score_atol(name):
+    """Two fp32 evaluations of the same network (the reference on ATen, this oracle on numpy / ATen kernels in another order) differ by
+    summation order alone.  Recipes A - D: <= 1.4e-4.  The confident-match fixtures (recipe E: residual rms 27 AND scores spread over
+    (0, 1), where d score / d logit is largest) have a wider fp32 floor — measured here (round 4): numpy 5.6e-4, ATen backend 4.4e-4,
+    and the float64 evaluation of the oracle is itself 7.1e-4 away from the reference's fp32 output (2048x512).  Indices are identical
+    in every case.  The 1e-3 bar therefore leaves the GPU path ~3e-4 of its own on those fixtures."""
+    return 7e-4 if name.startswith("trained_stats_confident") else 2e-4
+
+
 @pytest.mark.parametrize("name", golden_names())
 def test_oracle_matches_reference_golden(name):
     meta, gold = load_golden(name)
@@ -18,8 +27,9 @@ def test_oracle_matches_reference_golden(name):
     out = O.forward(sd, oracle_conf_for(case), data)
     np.testing.assert_array_equal(out["matches0"], gold["matches0"])
     np.testing.assert_array_equal(out["matches1"], gold["matches1"])
-    np.testing.assert_allclose(out["matching_scores0"], gold["matching_scores0"], atol=2e-4, rtol=0)
-    np.testing.assert_allclose(out["matching_scores1"], gold["matching_scores1"], atol=2e-4, rtol=0)
+    atol = oracle_score_atol(name)
+    np.testing.assert_allclose(out["matching_scores0"], gold["matching_scores0"], atol=atol, rtol=0)
+    np.testing.assert_allclose(out["matching_scores1"], gold["matching_scores1"], atol=atol, rtol=0)
     assert out["stop"] == gold["stop"].tolist()
     np.testing.assert_array_equal(np.asarray(out["prune0"], np.float32), gold["prune0"])
     np.testing.assert_array_equal(np.asarray(out["prune1"], np.float32), gold["prune1"])
@@ -32,7 +42,7 @@ def test_oracle_matches_reference_golden(name):
 # the torch-kernel backend of the oracle (the timed cpu_baseline leg of bench.py) is pinned against the same fixtures: small / edge cases,
 # both adaptive paths, trained statistics, 128-d and scale/orientation inputs, and the bench batch's own fixture
 TORCH_BACKEND_CASES = [n for n in golden_names() if any(t in n for t in ("bbox_300x200", "empty", "1x17", "5x3", "adaptive_9x30", "adaptive_1024",
-                                                                          "trained_stats_512", "sift", "disk128_256", "mutualnn", "nonadaptive_1024_b4"))]
+                                                                          "trained_stats_512", "trained_stats_confident_512", "trained_stats_confident_adaptive_1024", "sift", "disk128_256", "mutualnn", "nonadaptive_1024_b4"))]
 
 
 @pytest.mark.parametrize("name", TORCH_BACKEND_CASES)
@@ -42,8 +52,9 @@ def test_torch_backend_matches_reference_golden(name):
     out = O.forward(sd, oracle_conf_for(meta["case"]), data, backend="torch")
     np.testing.assert_array_equal(out["matches0"], gold["matches0"])
     np.testing.assert_array_equal(out["matches1"], gold["matches1"])
-    np.testing.assert_allclose(out["matching_scores0"], gold["matching_scores0"], atol=2e-4, rtol=0)
-    np.testing.assert_allclose(out["matching_scores1"], gold["matching_scores1"], atol=2e-4, rtol=0)
+    atol = oracle_score_atol(name)
+    np.testing.assert_allclose(out["matching_scores0"], gold["matching_scores0"], atol=atol, rtol=0)
+    np.testing.assert_allclose(out["matching_scores1"], gold["matching_scores1"], atol=atol, rtol=0)
     assert out["stop"] == gold["stop"].tolist()
     np.testing.assert_array_equal(np.asarray(out["prune0"], np.float32), gold["prune0"])
     np.testing.assert_array_equal(np.asarray(out["prune1"], np.float32), gold["prune1"])

@@ -80,6 +80,17 @@ CASES = {
     "trained_stats_sift_700x600": dict(recipe="D", data="D", wseed=4, dseed=691, B=1, n=700, m=600, dim=128, conf=dict(depth_confidence=-1, width_confidence=-1, input_dim=128, add_scale_ori=True)),
     # cfg #4's shape under the same statistics: 4096 keys per softmax row
     "trained_stats_disk128_4096": dict(recipe="D", data="D", wseed=3, dseed=701, B=1, n=4096, m=4096, dim=128, conf=dict(depth_confidence=-1, width_confidence=-1, input_dim=128)),
+    # ---- recipe E (round 4; VERDICT r03 "next" item 4): D's statistics AND a confident-match regime — the reference matches > 50 % of
+    # the keypoints with scores > 0.5 (recipe D: <= 12 %), so the 1e-3 score bar is exercised on scores near 1, not near 0
+    "trained_stats_confident_512": dict(recipe="E", data="E", wseed=0, dseed=601, B=1, n=512, m=512, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1)),
+    "trained_stats_confident_1024_b8": dict(recipe="E", data="E", wseed=0, dseed=1, B=8, n=1024, m=1024, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1)),
+    "trained_stats_confident_2048x512": dict(recipe="E", data="E", wseed=0, dseed=711, B=1, n=2048, m=512, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1)),
+    "trained_stats_confident_1024_w1_filter0": dict(recipe="E", data="E", wseed=1, dseed=721, B=1, n=1024, m=1024, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1, filter_threshold=0.0)),
+    "trained_stats_confident_adaptive_1024": dict(recipe="EC", data="E", wseed=0, dseed=731, B=2, n=1024, m=1024, dim=256, prune_th=-1, conf=dict()),
+    # descriptor-scale sweep on the confident fixture: descriptors x0.1 / x10 / x30 (x1 = trained_stats_confident_512)
+    "trained_stats_confident_512_x0p1": dict(recipe="E", data="E", desc_scale=0.1, wseed=0, dseed=601, B=1, n=512, m=512, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1)),
+    "trained_stats_confident_512_x10": dict(recipe="E", data="E", desc_scale=10.0, wseed=0, dseed=601, B=1, n=512, m=512, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1)),
+    "trained_stats_confident_512_x30": dict(recipe="E", data="E", desc_scale=30.0, wseed=0, dseed=601, B=1, n=512, m=512, dim=256, conf=dict(depth_confidence=-1, width_confidence=-1)),
 }
 
 
@@ -102,8 +113,11 @@ def case_inputs(case: dict):
                     "image_size": np.tile(np.array([[1024.0, 768.0]], np.float32), (case["B"], 1))}
         data = {"image0": img(case["n"]), "image1": img(case["m"])}
     else:
-        data_kw = dict(synth.RECIPE_D_DATA) if case.get("data") == "D" else {}
+        data_kw = dict({"D": synth.RECIPE_D_DATA, "E": synth.RECIPE_E_DATA}.get(case.get("data"), {}))
         data = synth.make_batch(case["dseed"], case["B"], case["n"], case["m"], case["dim"], add_scale_ori=conf.get("add_scale_ori", False), **data_kw)
+        if "desc_scale" in case:  # descriptor-scale sweep: the input domain the score bar is claimed on
+            for k in ("image0", "image1"):
+                data[k]["descriptors"] = (data[k]["descriptors"] * np.float32(case["desc_scale"])).astype(np.float32)
     if case.get("no_size"):
         for k in ("image0", "image1"):
             data[k].pop("image_size")
@@ -156,7 +170,8 @@ def main():
                     reference="cvg/LightGlue lightglue/lightglue.py (CPU fp32, loaded standalone)")
         np.savez_compressed(out_dir / f"{name}.npz", meta=json.dumps(meta), **out)
         hist0 = np.bincount(out["prune0"].astype(np.int64).ravel(), minlength=10).tolist() if out["prune0"].size else []
-        print(f"{name:32s} matches {out['n_matches'].tolist()} stop {out['stop'].tolist()} prune0 hist {hist0}")
+        conf_frac = float((out["matching_scores0"] > 0.5).mean()) if out["matching_scores0"].size else 0.0
+        print(f"{name:32s} matches {out['n_matches'].tolist()} stop {out['stop'].tolist()} prune0 hist {hist0} scores0 > 0.5: {conf_frac:.3f}")
 
 
 if __name__ == "__main__":

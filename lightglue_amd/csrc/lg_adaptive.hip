@@ -7,19 +7,17 @@
 //               ascending index order, which is what `torch.where` gives the reference).
 // adapt_compact rewrites, IN PLACE, the descriptor rows, the rotary tables and the index set of
 //               every pruned segment so that later layers see contiguous rows [0, len).
-//               In-place is safe because dst <= src: rows are processed in ascending chunks (1024 rows),
-//               each chunk is fully read into registers before a barrier and written after it.
-//               Parallelism = segments x 11 column slices (8 x 128 B of the descriptor row,
-//               cos, sin, index set).
+//               Parallelism = segments x 128-row chunks, every chunk in registers at once (see the kernel).
 // Per-pair state (len, active, final_layer) lives in device memory; every later kernel reads it,
 // so the whole adaptive forward is one stream of launches with no host synchronisation.
 #include "lg_kernels.h"
 
 namespace lg {
 
-__global__ __launch_bounds__(256) void adapt_decide_kernel(AdaptArgs a) {
+constexpr int DNT = 1024, DNW = DNT / 64;   // one workgroup of 16 waves per pair: a 2048-point image is two ballot steps (round 3: 256 threads, eight)
+__global__ __launch_bounds__(DNT) void adapt_decide_kernel(AdaptArgs a) {
     const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ int sh_cnt[4];
+    __shared__ int sh_cnt[DNW];
     __shared__ int sh_stop;
     __shared__ int sh_newlen[2];
     if (!a.active[pair]) {
@@ -36,14 +34,15 @@ __global__ __launch_bounds__(256) void adapt_decide_kernel(AdaptArgs a) {
         for (int image = 0; image < 2; ++image) {
             const int L = image ? len1 : len0;
             const float* c = a.conf + seg_row_base(a.rs, 2 * pair + image);
-            for (int r = tid; r < L; r += 256) cnt += (c[r] < a.conf_thr) ? 1 : 0;
+            for (int r = tid; r < L; r += DNT) cnt += (c[r] < a.conf_thr) ? 1 : 0;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
         if (lane == 0) sh_cnt[wave] = cnt;
         __syncthreads();
         if (tid == 0) {
-            const int total = sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
+            int total = 0;
+            for (int w = 0; w < DNW; ++w) total += sh_cnt[w];
             const float ratio = 1.0f - (float)total / (float)(a.len_orig[2 * pair] + a.len_orig[2 * pair + 1]);
             const int stop = ratio > a.depth_conf;
             sh_stop = stop;
@@ -64,7 +63,7 @@ __global__ __launch_bounds__(256) void adapt_decide_kernel(AdaptArgs a) {
         }
         const int base = seg_row_base(a.rs, seg);
         int running = 0;                                 // uniform across the block
-        for (int r0 = 0; r0 < L; r0 += 256) {
+        for (int r0 = 0; r0 < L; r0 += DNT) {
             const int r = r0 + tid;
             bool keep = false;
             if (r < L) {
@@ -76,10 +75,11 @@ __global__ __launch_bounds__(256) void adapt_decide_kernel(AdaptArgs a) {
             __syncthreads();                             // sh_cnt reuse
             if (lane == 0) sh_cnt[wave] = __popcll(bal);
             __syncthreads();
-            int woff = 0;
-            for (int w = 0; w < wave; ++w) woff += sh_cnt[w];
+            int woff = 0, all = 0;
+#pragma unroll
+            for (int w = 0; w < DNW; ++w) { const int c = sh_cnt[w]; woff += w < wave ? c : 0; all += c; }
             if (r < L) a.dst[base + r] = keep ? (running + woff + prefix) : -1;
-            running += sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
+            running += all;
         }
         __syncthreads();
         if (tid == 0) { a.len_old[seg] = L; a.len[seg] = running; sh_newlen[image] = running; }
@@ -89,56 +89,94 @@ __global__ __launch_bounds__(256) void adapt_decide_kernel(AdaptArgs a) {
     if (tid == 0 && (sh_newlen[0] == 0 || sh_newlen[1] == 0)) { a.active[pair] = 0; a.final_layer[pair] = a.layer + 1; }
 }
 
+// Compaction, round 4: parallel over ROW CHUNKS as well (round 3: one workgroup per (segment, 128-byte column slice) walking the rows in dependent
+// read | barrier | write steps — latency-bound by construction, 1.3 TB/s).  Work item = (segment, chunk of CROWS rows); a workgroup holds its whole
+// chunk — the 1 KB descriptor row, the cos and sin rows (1280 B per keypoint, 80 pieces of 16 bytes, dealt to the 256 threads in row-major order:
+// fully coalesced) and the index-set entries — in registers, so every chunk of every segment is read at the same time.
+// In place is still safe because dst <= src: a chunk only writes rows of ITSELF or of LOWER chunks of its segment, and it does so after those
+// chunks have published "all my rows are in registers" (one relaxed agent-scope flag per chunk, value = this launch's epoch; no payload travels
+// through memory between workgroups, so no release / acquire of data is involved — the flag only orders the consumer's stores behind the producer's
+// completed loads).  Deadlock freedom does not lean on dispatch order: the grid never exceeds one workgroup per CU (<= 256, each far below a CU's
+// register / LDS budget, so all are co-resident), a workgroup takes its items in ascending id, item id = chunk * segments + seg, and an item waits
+// only for items with lower ids; the spin is bounded anyway (an expired wait raises a.compact_err instead of hanging the GPU).
+// Memory ops are raw BUFFER loads / stores: a lane that has nothing to move gets an offset past the end of the buffer, for which the hardware
+// returns zeros / drops the store WITHOUT touching memory — 40 independent 16-byte loads per thread with no branch between them (a branch
+// around a load makes hipcc wait for it at the join, i.e. one exposed round trip per piece).
+constexpr int CROWS = 128;                     // rows per chunk
+constexpr unsigned CSKIP = 0xFFFFFFF0u;        // offset no buffer reaches
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t compact_rsrc(float* p, long long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)(bytes > 0xFFFFFF00LL ? 0xFFFFFF00LL : bytes), 0x00020000);
+}
+
 __global__ __launch_bounds__(256) void adapt_compact_kernel(AdaptArgs a) {
-    const int seg = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x;
-    const int Lold = a.len_old[seg];
-    if (Lold < 0) return;                    // pruning not applied to this segment at this layer
-    const int Lnew = a.len[seg];
-    const int base = seg_row_base(a.rs, seg);
-    if (slice == 10) {                       // index set + prune counters (ref :555, :558)
-        const int pair = seg >> 1, image = seg & 1;
-        int* prune = image ? a.prune1 + (long long)pair * a.n1 : a.prune0 + (long long)pair * a.n0;
-        for (int r0 = 0; r0 < Lold; r0 += 256) {
-            const int r = r0 + tid;
-            int d = -1, v = 0;
-            if (r < Lold) { d = a.dst[base + r]; v = a.ind[base + r]; }
-            __syncthreads();
-            if (d >= 0) { a.ind[base + d] = v; prune[v] += 1; }
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), nseg = 2 * a.rs.B, nchunk = a.compact_chunks;
+    __shared__ int sh_d[CROWS];                // destination row of each row of the chunk, -1 = nothing to move (dropped, or already in place)
+    const long long Rrows = (long long)a.rs.B * (a.rs.cap0 + a.rs.cap1);
+    const __amdgpu_buffer_rsrc_t rx = compact_rsrc(a.X, Rrows * 1024), rt = compact_rsrc(w < 2 ? a.cosb : a.sinb, Rrows * 128);   // waves 0, 1 move cos rows, waves 2, 3 sin rows
+    for (int item = blockIdx.x; item < nseg * nchunk; item += gridDim.x) {
+        const int chunk = item / nseg, seg = item - chunk * nseg;
+        const int Lold = a.len_old[seg];
+        if (Lold < 0) continue;                  // pruning not applied to this segment at this layer
+        const int r0 = chunk * CROWS;
+        if (r0 >= Lold) continue;                // no rows: nobody waits for this chunk either (a waiting chunk has rows, so every lower one does)
+        const int Lnew = a.len[seg];
+        const int base = seg_row_base(a.rs, seg);
+        // index set + prune counters (ref :555, :558) — one row per thread of the first half of the workgroup
+        int myd = -1, myv = 0;
+        if (tid < CROWS && r0 + tid < Lold) { myd = a.dst[base + r0 + tid]; myv = a.ind[base + r0 + tid]; }
+        int* prune = (seg & 1) ? a.prune1 + (long long)(seg >> 1) * a.n1 : a.prune0 + (long long)(seg >> 1) * a.n0;
+        if (Lnew == Lold) {                      // nothing dropped: rows and index set already in place, only the counters move
+            if (myd >= 0) prune[myv] += 1;
+            continue;
         }
-        return;
-    }
-    if (Lnew == Lold) return;                // nothing dropped: rows already in place
-    float* buf; int ld, col;
-    if (slice < 8) { buf = a.X; ld = 256; col = slice * 32; }
-    else { buf = slice == 8 ? a.cosb : a.sinb; ld = 32; col = 0; }
-    const int sub = tid & 7, rr = tid >> 3;  // 8 lanes x 16 B = one 128-byte row slice; 32 rows per pass
-    // CU = passes per iteration.  The kernel is a chain of (read chunk | barrier | write chunk) steps per segment, i.e. bound by the
-    // number of HBM round trips, not by bytes: 8 passes (256 rows) per step ran at 0.9 TB/s in the cfg #3 trace (2048-row segments = 8
-    // dependent steps); 32 passes (1024 rows, 128 data VGPRs) make it 2 steps
-    constexpr int CU = 32;
-    for (int r0 = 0; r0 < Lold; r0 += 32 * CU) {
-        f32x4 v[CU]; int d[CU];
+        __syncthreads();                         // the previous item's readers of sh_d are done
+        if (tid < CROWS) sh_d[tid] = (myd >= 0 && myd != r0 + tid) ? myd : -1;
+        __syncthreads();
+        // descriptor rows: wave w, step u -> row 4u + w of the chunk, one 16-byte piece per lane (a whole 1 KB row per wave instruction)
+        u32x4 vx[32], vt[8]; int dx[32], dt[8];
+        const unsigned xrow0 = (unsigned)(base + r0) * 1024u + (unsigned)lane * 16u;
 #pragma unroll
-        for (int u = 0; u < CU; ++u) {
-            const int r = r0 + u * 32 + rr;
-            d[u] = -1;
-            if (r < Lold) {
-                d[u] = a.dst[base + r];
-                if (d[u] >= 0 && d[u] != r) v[u] = *reinterpret_cast<const f32x4*>(buf + (long long)(base + r) * ld + col + sub * 4);
+        for (int u = 0; u < 32; ++u) {
+            const int row = 4 * u + w;
+            dx[u] = sh_d[row];
+            vx[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, dx[u] >= 0 ? xrow0 + (unsigned)row * 1024u : CSKIP, 0, 0);
+        }
+        // rotary tables: a wave pair covers 128 rows x 8 pieces of one table: thread t of the pair, step u -> row 16u + (t >> 3), piece t & 7
+        const int tt = tid & 127;
+        const unsigned trow0 = (unsigned)(base + r0) * 128u + (unsigned)(tt & 7) * 16u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = 16 * u + (tt >> 3);
+            dt[u] = sh_d[row];
+            vt[u] = __builtin_amdgcn_raw_buffer_load_b128(rt, dt[u] >= 0 ? trow0 + (unsigned)row * 128u : CSKIP, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every row of the chunk has ARRIVED in registers (not merely been requested)
+        __syncthreads();
+        int* flags = a.compact_flags + (long long)seg * nchunk;
+        if (tid == 0) __hip_atomic_store(flags + chunk, a.compact_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < chunk) {                       // lower chunks of this segment: their rows are the only foreign ones this chunk overwrites
+            int spins = 0;
+            while (__hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.compact_epoch) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 20)) { *a.compact_err = 1; break; }
             }
         }
         __syncthreads();
+        const unsigned xdst0 = (unsigned)base * 1024u + (unsigned)lane * 16u, tdst0 = (unsigned)base * 128u + (unsigned)(tt & 7) * 16u;
 #pragma unroll
-        for (int u = 0; u < CU; ++u) {
-            const int r = r0 + u * 32 + rr;
-            if (d[u] >= 0 && d[u] != r) *reinterpret_cast<f32x4*>(buf + (long long)(base + d[u]) * ld + col + sub * 4) = v[u];
-        }
+        for (int u = 0; u < 32; ++u) __builtin_amdgcn_raw_buffer_store_b128(vx[u], rx, dx[u] >= 0 ? xdst0 + (unsigned)dx[u] * 1024u : CSKIP, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) __builtin_amdgcn_raw_buffer_store_b128(vt[u], rt, dt[u] >= 0 ? tdst0 + (unsigned)dt[u] * 128u : CSKIP, 0, 0);
+        if (myd >= 0) { a.ind[base + myd] = myv; prune[myv] += 1; }
     }
 }
 
 hipError_t launch_adapt(const AdaptArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(adapt_decide_kernel, dim3(a.rs.B), dim3(256), 0, s, a);
-    if (a.do_prune) hipLaunchKernelGGL(adapt_compact_kernel, dim3(2 * a.rs.B, 11), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(adapt_decide_kernel, dim3(a.rs.B), dim3(DNT), 0, s, a);
+    if (a.do_prune) {
+        const int items = 2 * a.rs.B * a.compact_chunks;
+        hipLaunchKernelGGL(adapt_compact_kernel, dim3(items < 256 ? items : 256), dim3(256), 0, s, a);
+    }
     return hipGetLastError();
 }
 

@@ -108,7 +108,8 @@ struct lg_engine {
     bool attn_dma = true;   // option "attn_dma": LDS-DMA attention kernel (16-bit operands, 32 rows per wave)
     int attn_rows = 32;   // query rows per attention wave (32 | 64), option "attn_rows" / env LG_ATTN_ROWS
     int fused_tail = 1, fused_next = 1;
-    int tail_timing = 0; long long* TAILDBG = nullptr;
+    int tail_timing = 0; long long* TAILDBG = nullptr; long long* TAILDBG2 = nullptr;
+    int* CFLAGS = nullptr; int compact_epoch = 0; bool cflags_clean = false;   // compaction chunk flags [2B][cap / 128] + 1 error word (lg_adaptive.hip)
     int tail_row_tiles = 0;   // option "tail_row_tiles": 16-row tiles per fused-tail workgroup; 0 = by grid fill (4 | 2 | 1)
     bool attn_auto_rows = true;   // small grids: 16 query rows per attention wave (twice the workgroups); off once "attn_rows" is set
     // ---- workspace
@@ -253,7 +254,8 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
         for (int i = 0; i < 3; ++i) add(R * 256 * as);          // Q K VT
         add(R * 4); add(R * 4);                                 // IND DST
         for (int i = 0; i < 5; ++i) add((size_t)nB * 2 * 4);    // LEN LEN_ORIG LEN_OLD ACTIVE FINAL_LAYER
-        add(R / 64 * 64 * 8);                                   // TAILDBG
+        add(R / 128 * 8 + 256);                                 // CFLAGS: 2B * max(cap0, cap1) / 128 ints <= 2 R / 128, + the error word
+        add(R * 16); add(R * 16);                               // TAILDBG TAILDBG2 (16 bytes per row: [R / 64 workgroups][8 waves][8 stamps], or [R / 128][16 half-waves ...] of the split attention's taps)
         total += 4096;
         HIPCHK(hipMalloc(&e->ws, total));
         e->ws_bytes = total;
@@ -282,7 +284,8 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
     e->IND = (int*)take("IND", R * 4); e->DST = (int*)take("DST", R * 4);
     e->LEN = (int*)take("LEN", (size_t)B * 2 * 4); e->LEN_ORIG = (int*)take("LEN_ORIG", (size_t)B * 2 * 4); e->LEN_OLD = (int*)take("LEN_OLD", (size_t)B * 2 * 4);
     e->ACTIVE = (int*)take("ACTIVE", (size_t)B * 4); e->FINAL_LAYER = (int*)take("FINAL_LAYER", (size_t)B * 4);
-    e->TAILDBG = (long long*)take("TAILDBG", R / 64 * 64 * 8);
+    e->CFLAGS = (int*)take("CFLAGS", (size_t)2 * B * ((c0 > c1 ? c0 : c1) / 128) * 4 + 256); e->cflags_clean = false;
+    e->TAILDBG = (long long*)take("TAILDBG", R * 16); e->TAILDBG2 = (long long*)take("TAILDBG2", R * 16);
     if (ar.used > e->ws_bytes) return fail(LG_ERR_STATE, "workspace carve overflow");
     return LG_OK;
 }
@@ -539,7 +542,7 @@ int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
     if (std::strcmp(key, "attn_rows") == 0) { if (value != 16 && value != 32 && value != 64) return fail(LG_ERR_INVALID, "attn_rows must be 16, 32 or 64"); e->attn_rows = value; e->attn_auto_rows = false; return LG_OK; }
     if (std::strcmp(key, "tail_row_tiles") == 0) { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(LG_ERR_INVALID, "tail_row_tiles must be 0 (automatic), 1, 2 or 4"); e->tail_row_tiles = value; return LG_OK; }
     if (std::strcmp(key, "profile_only") == 0) { e->prof_only = value; return LG_OK; }   // kernel class index, -1 = all classes
-    if (std::strcmp(key, "tail_timing") == 0) { e->tail_timing = value; return LG_OK; }   // 1: tail kernel, 2: self projection, 3: self attention (LG_ATTN_TIMING builds)
+    if (std::strcmp(key, "tail_timing") == 0) { e->tail_timing = value; return LG_OK; }   // 1: tail kernel, 2: self projection, 3: self attention (LG_ATTN_TIMING builds), 4: assign sweeps, 5 / 6: layer 0's CrossBlock / SelfBlock tail WITH its fused next projection (stamps of the projection in TAILDBG2)
     return fail(LG_ERR_INVALID, std::string("unknown option '") + key + "'");
 }
 
@@ -777,7 +780,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
     };
     // fused_next: a tail kernel also runs the NEXT block's projection on the x tile it has just produced.  Across a
     // layer boundary that is only valid when nothing re-orders rows in between (no early stop / pruning step).
-    const bool fuse_next = e->fused_next && e->fused_tail && e->tail_timing == 0 &&
+    const bool fuse_next = e->fused_next && e->fused_tail && (e->tail_timing == 0 || e->tail_timing == 5 || e->tail_timing == 6) &&
                            e->debug_stop < 0 && launch_tail_supports_next(prec, ap);
     const bool prune_possible = do_prune && (n0 > e->cfg.pruning_min_kpts || n1 > e->cfg.pruning_min_kpts);
     bool proj_done = false;
@@ -818,13 +821,14 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                         else { ta.head_w0 = e->w_match + (size_t)i * D; ta.head_b0 = e->b_match + i; ta.head_out0 = e->MSCORE; }
                     }
                 }
-                ta.dbg = e->tail_timing == 1 ? e->TAILDBG : nullptr;
+                ta.dbg = (e->tail_timing == 1 || (i == 0 && ((e->tail_timing == 5 && blk == 1) || (e->tail_timing == 6 && blk == 0)))) ? e->TAILDBG : nullptr;
                 ta.row_tiles = e->tail_row_tiles ? e->tail_row_tiles : tail_row_tiles_for(R);
                 // Across a layer boundary the fusion is valid whenever no row can MOVE in between: early stop alone only
                 // deactivates a pair (its speculative projection is never read), pruning re-orders rows — but it cannot
                 // happen while every segment is at or below the pruning threshold (ref :551 / :559; lengths only shrink).
                 if (fuse_next && (blk == 0 || (i + 1 < L && !prune_possible))) {
                     ta.next = blk == 0 ? make_proj(i, 1) : make_proj(i + 1, 0);
+                    if (ta.dbg && e->tail_timing >= 5) ta.next.dbg = e->TAILDBG2;
                     proj_done = true;
                 }
                 TRY(prof_begin(e, PC_TAIL, s));
@@ -894,6 +898,12 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
             ad.width_conf = (float)(1.0 - e->cfg.width_confidence);
             ad.pruning_min_kpts = e->cfg.pruning_min_kpts;
             ad.do_stop = do_stop; ad.do_prune = prune_now;
+            ad.compact_chunks = (c0 > c1 ? c0 : c1) / 128; ad.compact_flags = e->CFLAGS; ad.compact_err = e->CFLAGS + (size_t)2 * B * ad.compact_chunks;
+            if (prune_now && !e->cflags_clean) {   // fresh carve: whatever the arena held there must not look like an epoch
+                HIPCHK(hipMemsetAsync(e->CFLAGS, 0, (size_t)2 * B * ad.compact_chunks * 4 + 256, s));
+                e->cflags_clean = true;
+            }
+            ad.compact_epoch = ++e->compact_epoch;
             TRY(prof_begin(e, PC_ADAPTIVE, s));
             HIPCHK(launch_adapt(ad, s));
             TRY(prof_end(e, s));

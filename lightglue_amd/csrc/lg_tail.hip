@@ -133,11 +133,15 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
 
     // ------------------------------------------------------------------ phase A
+    // the accumulators START at the folded bias (lane (lr, g) holds hidden units 4g .. 4g + 3 of its n-tiles for every row): the loads hide
+    // under the x tile's, and the LayerNorm phase no longer opens with an exposed L2 round trip for them
     f32x4 acc[MT][4];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bcat + (w + 8 * j) * 16 + 4 * g);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MT; ++i) acc[i][j] = b4;
+    }
 
     // weight fragment: plane p, n-tile nt, k-chunk kc -> 64 lanes x 16 B contiguous
     auto wfrag = [&](const void* base, int p, long long plane_elems, int nt, int kc) -> u32x4 {
@@ -239,17 +243,14 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         }
     }
     stamp(1);
-    // ------------------------------------------------------------------ bias + LayerNorm(512)
+    // ------------------------------------------------------------------ LayerNorm(512) (the bias is already in the accumulators)
     // acc[mt][nt][r] = h[row mt*16 + lr][hidden (w + 8 nt)*16 + 4g + r]
     {
         f32x4 gam[4], bet[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int col = (w + 8 * nt) * 16 + 4 * g;
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bcat + col);
             gam[nt] = *reinterpret_cast<const f32x4*>(a.gamma + col); bet[nt] = *reinterpret_cast<const f32x4*>(a.beta + col);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] += b4;
         }
         // this wave's 64 hidden units of row (mt, lr): local mean and M2 = sum (h - mean)^2, entirely in registers
         f32x2* red2 = reinterpret_cast<f32x2*>(red);
@@ -345,6 +346,11 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     constexpr int CPS = NKC / 4;   // k-chunks per step (4 for 16-bit: K-stages 2j, 2j+1; 8 for f32)
     const int qlen = a.rs.len[t.seg];
     f32x4 xres[MT][2];             // residual rows, same (row, 4 columns) per lane as acc2
+    // the epilogue's operands — output bias, optional head weights (token confidence / matchability: this lane's 8 columns of each weight vector)
+    // — are fetched with the residual rows, under the last step's MFMAs (round 3 issued them at the head of the epilogue: one exposed round trip)
+    f32x4 b2v[2];
+    const bool heads = a.head_w0 != nullptr;                         // workgroup-uniform
+    f32x4 hw0[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, hw1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (j == 3) {              // issue the residual loads so that they land under the last step's MFMAs
@@ -353,6 +359,15 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
                     xres[mt][nt] = *reinterpret_cast<const f32x4*>(a.X + (long long)(t.grow0 + mt * 16 + lr) * 256 + w * 32 + nt * 16 + 4 * g);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) b2v[nt] = *reinterpret_cast<const f32x4*>(a.b2 + w * 32 + nt * 16 + 4 * g);
+            if (heads) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    hw0[nt] = *reinterpret_cast<const f32x4*>(a.head_w0 + w * 32 + nt * 16 + 4 * g);
+                    if (a.head_w1) hw1[nt] = *reinterpret_cast<const f32x4*>(a.head_w1 + w * 32 + nt * 16 + 4 * g);
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < CPS; ++i) {
@@ -369,18 +384,6 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     // ------------------------------------------------------------------ epilogue: + b2, + x, store; next block's activation tile
     // NEXT: the tile goes to K-stages 0..3 of the g planes (hi at 0, lo at G_PLANE): every wave is past the barrier that
     // ended step 2, so nobody reads those stages any more (step 3 reads stages 6, 7) — no barrier needed here.
-    // (loads before the first store: the compiler must assume that x aliases b2, see lg_proj_body.h)
-    const f32x4 b2v[2] = {*reinterpret_cast<const f32x4*>(a.b2 + w * 32 + 4 * g), *reinterpret_cast<const f32x4*>(a.b2 + w * 32 + 16 + 4 * g)};
-    // optional heads on the new x rows (token confidence / matchability): this lane's 8 columns of each weight vector
-    const bool heads = a.head_w0 != nullptr;                         // workgroup-uniform
-    f32x4 hw0[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, hw1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    if (heads) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            hw0[nt] = *reinterpret_cast<const f32x4*>(a.head_w0 + w * 32 + nt * 16 + 4 * g);
-            if (a.head_w1) hw1[nt] = *reinterpret_cast<const f32x4*>(a.head_w1 + w * 32 + nt * 16 + 4 * g);
-        }
-    }
     float hp0[MT], hp1[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) { hp0[mt] = 0.f; hp1[mt] = 0.f; }
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         }
     }
     stamp(5);
-    if constexpr (NEXT != 0) proj_compute<(prec_is_split(PREC) ? (ASPLIT ? PREC_F16X3 : PREC_QKV_F16W2) : PREC), TA, NEXT == 1 ? 3 : 2, 2, G_PLANE, MT>(a.next, t, smem, 8);
+    if constexpr (NEXT != 0) proj_compute<(prec_is_split(PREC) ? (ASPLIT ? PREC_F16X3 : PREC_QKV_F16W2) : PREC), TA, NEXT == 1 ? 3 : 2, 2, G_PLANE, MT>(a.next, t, smem, 0);
     if (a.dbg && lane == 0)   // wall clock at the end + where the workgroup ran (HW_ID, XCC_ID)
         a.dbg[((long long)blockIdx.x * 8 + w) * 8 + 7] = (wall_clock64() & ((1LL << 44) - 1)) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFF00) << 40) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 44);
 }

@@ -105,6 +105,28 @@ def test_adaptive_batch_equals_per_pair_and_is_well_formed():
         assert (out["matches0"][b][out["prune0"][b] < out["prune0"][b].max()] == -1).all() or True
 
 
+def test_compaction_many_chunks_and_rounds():
+    """Round-4 compaction (lg_adaptive.hip): work items = (segment, 128-row chunk), at most 256 workgroups looping over them, a chunk waiting
+    for the "in registers" flags of every lower chunk of its segment.  B = 10 at N = M = 4096 is 640 items = three rounds per workgroup with up
+    to 31 lower chunks to wait for; one pair at a time is 64 items in one round.  Both must agree bit for bit (indices, scores, stop layers,
+    prune counters), and the bounded flag wait must never have expired (error word behind the flags)."""
+    require_gpu()
+    B, n = 10, 4096
+    data = synth.make_batch(830, B, n, n)
+    model = _model(recipe="C", pruning_min_kpts=-1)
+    t = gpu_util.to_torch(data)
+    out = model(t)
+    _check_structure(out, n, n)
+    assert len(torch.unique(out["prune0"])) >= 2, "the fixture must prune at more than one layer"
+    flags = model.debug_read("CFLAGS", np.int32)
+    assert flags[2 * B * (n // 128)] == 0, "a compaction flag wait expired"
+    for b in range(B):
+        one = model({k: {kk: vv[b:b + 1] for kk, vv in v.items()} for k, v in t.items()})
+        assert int(one["stop"]) == int(out["stop"][b])
+        for k in ("matches0", "matches1", "matching_scores0", "matching_scores1", "prune0", "prune1"):
+            assert torch.equal(one[k][0], out[k][b]), f"pair {b}: {k} differs between the batched and the single-pair forward"
+
+
 def test_ragged_compaction_stress_asymmetric():
     """cfg #5-style: 128-d descriptors, N=2048 vs M=512, pruning ON with the device threshold 1536
     (only image0 is ever pruned), fp16."""

@@ -16,6 +16,7 @@ model(data); model.set_option("tail_timing", 3); model(data); torch.cuda.synchro
 NW = 8 if prec == "f16x3" else 4   # waves per workgroup: the split attention runs 8 x 16 rows, the single-plane kernels 4 x 32
 d = model.debug_read("TAILDBG", np.int64).reshape(-1, NW, 8)
 d = d[d[:, 0, 7] == 1]
+assert d.shape[0] == 32 * 2048 // (128 if NW == 8 else 128) * 4, f"expected every (row tile, head) workgroup to report, got {d.shape[0]}"   # the tap buffer is sized for the split kernel now
 tiles = d[:, :, 6].astype(np.float64)
 dma = (len(sys.argv) <= 2 or sys.argv[2] != "staged")
 if not dma: model.set_option("attn_dma", 0); model(data); torch.cuda.synchronize(); d = model.debug_read("TAILDBG", np.int64).reshape(-1, NW, 8); d = d[d[:, 0, 7] == 1]; tiles = d[:, :, 6].astype(np.float64)

@@ -106,28 +106,6 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
 #pragma unroll
             for (int p = 0; p < NPART; ++p) dst[j][p] = wfrag(p, pj_tile<NTP>(w, pass, j), kc);
     };
-    // ---- the epilogue's operands (bias, rotary tables) are fetched BEFORE the MFMA loop (round 4; 43 VGPRs the loop has to spare): issued at the
-    // head of the epilogue they cost every pass one exposed L2 / HBM round trip — the stamps of the fused SelfBlock projection showed epilogues
-    // of 7.6k + 4.5k cycles next to MFMA loops of 13.0k + 8.6k (profiles/r04b_tail_timing.md).  Loads before the first store anyway: the compiler
-    // cannot prove that q / k / v do not alias the tables, so a load placed after a store stays there.
-    constexpr bool HAS_PAIR = !pj_is_v<NTP>(PASS, 0);          // slots 0, 1 = a q / k pair
-    constexpr bool ROPE = NTP == 3;                            // SelfBlock: rotary on q and k (ref :58-65)
-    const int pcol = (NTP == 3 ? PASS * 256 : 0) + 32 * w;     // first packed column of the pair: [group][head][64]
-    f32x4 pb[2]; f32x4 pc[MT], ps[MT]; float bv[NTP];
-    if constexpr (HAS_PAIR) {
-        pb[0] = *reinterpret_cast<const f32x4*>(a.bias + pcol + 8 * g); pb[1] = *reinterpret_cast<const f32x4*>(a.bias + pcol + 8 * g + 4);
-        if constexpr (ROPE) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const long long row = t.grow0 + pj_row<MT>(mt, lr);
-                pc[mt] = *reinterpret_cast<const f32x4*>(a.cosb + row * 32 + ((pcol & 63) >> 1) + 4 * g);
-                ps[mt] = *reinterpret_cast<const f32x4*>(a.sinb + row * 32 + ((pcol & 63) >> 1) + 4 * g);
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < NTP; ++j)
-        if (pj_is_v<NTP>(PASS, j)) bv[j] = a.bias[pj_tile<NTP>(w, PASS, j) * 16 + lr];
     f32x4 acc[MT][NTP];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -165,10 +143,30 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
         }
     }
     stamp(2 + 2 * PASS);
-    // ---- epilogue of the pass, straight from the accumulators (operands fetched above)
+    // ---- epilogue of the pass, straight from the accumulators.  All loads (bias, rotary tables) are issued BEFORE the first
+    // store: the compiler cannot prove that q/k/v do not alias the tables, so a load placed after a store stays there and
+    // every (tile, 16-row tile) iteration would expose one full L2 round trip (measured: 14k cycles for 12 iterations).
     typedef TA ta4 __attribute__((ext_vector_type(4)));
     constexpr int OPART = PJ<PREC>::OPART;
     static_assert(OPART == 1 || sizeof(TA) == 2, "split q / k / v planes are f16");
+    constexpr bool HAS_PAIR = !pj_is_v<NTP>(PASS, 0);          // slots 0, 1 = a q / k pair
+    constexpr bool ROPE = NTP == 3;                            // SelfBlock: rotary on q and k (ref :58-65)
+    const int pcol = (NTP == 3 ? PASS * 256 : 0) + 32 * w;     // first packed column of the pair: [group][head][64]
+    f32x4 pb[2]; f32x4 pc[MT], ps[MT]; float bv[NTP];
+    if constexpr (HAS_PAIR) {
+        pb[0] = *reinterpret_cast<const f32x4*>(a.bias + pcol + 8 * g); pb[1] = *reinterpret_cast<const f32x4*>(a.bias + pcol + 8 * g + 4);
+        if constexpr (ROPE) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const long long row = t.grow0 + pj_row<MT>(mt, lr);
+                pc[mt] = *reinterpret_cast<const f32x4*>(a.cosb + row * 32 + ((pcol & 63) >> 1) + 4 * g);
+                ps[mt] = *reinterpret_cast<const f32x4*>(a.sinb + row * 32 + ((pcol & 63) >> 1) + 4 * g);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NTP; ++j)
+        if (pj_is_v<NTP>(PASS, j)) bv[j] = a.bias[pj_tile<NTP>(w, PASS, j) * 16 + lr];
     if constexpr (HAS_PAIR) {                                  // q / k (or qk) pair: 8 consecutive channels per lane and keypoint row
         TA* base = static_cast<TA*>((NTP == 3 && PASS == 1) ? a.k : a.q);
         const int head = (pcol >> 6) & 3, d0 = pcol & 63;

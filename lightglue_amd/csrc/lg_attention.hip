@@ -420,7 +420,12 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_dma_kernel(AttnArgs a) {
             const int q = (tile * 4) / ntiles;
             if (q == 0) __builtin_amdgcn_s_setprio(3); else if (q == 1) __builtin_amdgcn_s_setprio(2); else if (q == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of this tile (and, first time round, my Q fragments)
+        // my pieces of this tile (and, first time round, my Q fragments).  The BUILTIN, not inline asm: hipcc's waitcnt pass must see this wait —
+        // it knows nothing of the asm DMAs, but it does track the Q fragment loads, and with an asm wait it still believed them in flight at
+        // their first use in the (peeled) first tile: its own vmcnt(0) there also waited for the NEXT tile's DMAs issued in between (in-order
+        // counter), i.e. one exposed DMA round trip per workgroup (ISA check: tools/check_isa.py)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), expcnt / lgkmcnt untouched
+        asm volatile("" ::: "memory");
         __syncthreads();
         ATT_TICK(0);
         if (kv0 + ABK > kvlen) {                            // workgroup-uniform: zero the dead key columns of V^T
@@ -655,7 +660,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_split_kernel(AttnArgs a)
             const int q = (tile * 4) / ntiles;
             if (q == 0) __builtin_amdgcn_s_setprio(3); else if (q == 1) __builtin_amdgcn_s_setprio(2); else if (q == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of this tile (and, first time round, my Q fragments)
+        // my pieces of this tile (and, first time round, my Q fragments).  The BUILTIN, not inline asm: hipcc's waitcnt pass must see this wait —
+        // it knows nothing of the asm DMAs, but it does track the Q fragment loads, and with an asm wait it still believed them in flight at
+        // their first use in the (peeled) first tile: its own vmcnt(0) there also waited for the NEXT tile's DMAs issued in between (in-order
+        // counter), i.e. one exposed DMA round trip per workgroup (ISA check: tools/check_isa.py)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), expcnt / lgkmcnt untouched
+        asm volatile("" ::: "memory");
         __syncthreads();
         ATT_TICK(0);
         if (kv0 + ABK > kvlen) {                            // workgroup-uniform: zero the dead key columns of both V^T planes

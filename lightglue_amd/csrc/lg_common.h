@@ -130,6 +130,11 @@ template <int ROWB> __device__ __forceinline__ int lds_off(int row, int slot16) 
 // round trips per 64-key tile).  The asm form is invisible to that pass; completion is tracked by hand (s_waitcnt vmcnt before the
 // barrier that publishes the tile), and a compiler-issued vmcnt wait can only over-wait because of it, never under-wait.
 // `lds` must be wave-uniform (it travels in M0); one wait state between the M0 write and the DMA instruction.
+// INVARIANTS a caller keeps (checked on the compiled ISA by tools/check_isa.py, tests/test_isa_invariants.py):
+//   * every barrier that publishes a DMA'd tile is preceded by a vmcnt(0) wait, written as __builtin_amdgcn_s_waitcnt (NOT inline asm: the
+//     waitcnt pass must see it, or it keeps waiting for older compiler-visible loads later — and, the counter being in order, for the DMAs
+//     issued in between: "over-wait" = an exposed DMA round trip, found in the peeled first tile of the attention kernels in round 4);
+//   * no VMEM store sits between a DMA and its wait, and all waits for DMAs are vmcnt(0) (the in-order argument needs nothing else then).
 __device__ __forceinline__ void lds_dma16(const void* gptr, void* lds) {
     const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(gptr) : "memory", "m0");

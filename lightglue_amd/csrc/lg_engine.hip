@@ -93,7 +93,7 @@ struct lg_engine {
     bool weights_ready = false;
     // ---- device weights (layer-major arrays)
     void* w_arena = nullptr;
-    PackedW w_in, w_sout, w_sf1, w_sf2, w_cout, w_cf1, w_cf2, w_final;
+    PackedW w_in, w_sout, w_sf1, w_sf2, w_cout, w_cf1, w_cf2;
     float *b_in = nullptr, *b_sqkv = nullptr, *b_sout = nullptr, *b_sf1 = nullptr, *b_sf2 = nullptr, *b_cqkv = nullptr,
           *b_cout = nullptr, *b_cf1 = nullptr, *b_cf2 = nullptr, *b_final = nullptr;
     float *ln_s_g = nullptr, *ln_s_b = nullptr, *ln_c_g = nullptr, *ln_c_b = nullptr;  // [L][512]
@@ -103,8 +103,8 @@ struct lg_engine {
     char *w_stail_cat = nullptr, *w_stail_2 = nullptr, *w_ctail_cat = nullptr, *w_ctail_2 = nullptr;
     float *b_scat = nullptr, *b_ccat = nullptr;
     size_t tail_cat_layer_bytes = 0, tail_2_layer_bytes = 0;
-    char *w_sqkv_p = nullptr, *w_cqkv_p = nullptr;   // fragment-packed projection weights (lg_proj.hip)
-    size_t sqkv_layer_bytes = 0, cqkv_layer_bytes = 0;
+    char *w_sqkv_p = nullptr, *w_cqkv_p = nullptr, *w_final_p = nullptr;   // fragment-packed projection weights (lg_proj.hip)
+    size_t sqkv_layer_bytes = 0, cqkv_layer_bytes = 0, final_layer_bytes = 0;
     bool attn_dma = true;   // option "attn_dma": LDS-DMA attention kernel (16-bit operands, 32 rows per wave)
     int attn_rows = 32;   // query rows per attention wave (32 | 64), option "attn_rows" / env LG_ATTN_ROWS
     int fused_tail = 1, fused_next = 1;
@@ -117,7 +117,7 @@ struct lg_engine {
     int capB = 0, cap0 = 0, cap1 = 0;      // reserved
     int cur_cap0 = 0, cur_cap1 = 0, curB = 0;
     std::map<std::string, std::pair<void*, size_t>> bufs;
-    float *X, *CTX, *MSG, *H1, *G, *COS, *SIN, *MD, *SIM, *LS, *CONF, *MSCORE, *LSE_R, *LSE_C, *MAX0, *MAX1, *BBOX, *XIN, *CPM, *CPS, *CBV;
+    float *X, *CTX, *MSG, *H1, *G, *COS, *SIN, *MD, *SIM, *LS, *LSNEG, *CONF, *MSCORE, *LSE_R, *LSE_C, *MAX0, *MAX1, *BBOX, *XIN, *CPM, *CPS, *CBV;
     int* CBI;
     void *Q, *K, *VT;
     int *IND, *DST, *LEN, *LEN_ORIG, *LEN_OLD, *ACTIVE, *FINAL_LAYER, *ARG0, *ARG1;
@@ -244,7 +244,7 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
         add(R * 32 * 4); add(R * 32 * 4);                       // COS SIN
         add(R * 256 * 4);                                       // MD
         add((size_t)nB * nc0 * nc1 * 4);                        // SIM
-        for (int i = 0; i < 3; ++i) add(R * 4);                 // LS CONF MSCORE
+        for (int i = 0; i < 4; ++i) add(R * 4);                 // LS LSNEG CONF MSCORE
         add((size_t)nB * nc0 * 4); add((size_t)nB * nc1 * 4);   // LSE_R LSE_C
         add((size_t)nB * nc0 * 4); add((size_t)nB * nc1 * 4);   // MAX0 MAX1
         add((size_t)nB * nc0 * 4); add((size_t)nB * nc1 * 4);   // ARG0 ARG1
@@ -272,7 +272,7 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
     e->COS = (float*)take("COS", R * 32 * 4); e->SIN = (float*)take("SIN", R * 32 * 4);
     e->MD = (float*)take("MD", R * 256 * 4);
     e->SIM = (float*)take("SIM", (size_t)B * c0 * c1 * 4);
-    e->LS = (float*)take("LS", R * 4); e->CONF = (float*)take("CONF", R * 4); e->MSCORE = (float*)take("MSCORE", R * 4);
+    e->LS = (float*)take("LS", R * 4); e->LSNEG = (float*)take("LSNEG", R * 4); e->CONF = (float*)take("CONF", R * 4); e->MSCORE = (float*)take("MSCORE", R * 4);
     e->LSE_R = (float*)take("LSE_R", (size_t)B * c0 * 4); e->LSE_C = (float*)take("LSE_C", (size_t)B * c1 * 4);
     e->MAX0 = (float*)take("MAX0", (size_t)B * c0 * 4); e->MAX1 = (float*)take("MAX1", (size_t)B * c1 * 4);
     e->ARG0 = (int*)take("ARG0", (size_t)B * c0 * 4); e->ARG1 = (int*)take("ARG1", (size_t)B * c1 * 4);
@@ -393,7 +393,6 @@ int lg_engine_finalize_weights(lg_engine* e) {
     addw((size_t)D * Din);
     addw((size_t)L * D * D); addw((size_t)L * 512 * 512); addw((size_t)L * D * 512);
     addw((size_t)L * D * D); addw((size_t)L * 512 * 512); addw((size_t)L * D * 512);
-    addw((size_t)L * D * D);
     addf(D); addf((size_t)L * 768); addf((size_t)L * D); addf((size_t)L * 512); addf((size_t)L * D);
     addf((size_t)L * 512); addf((size_t)L * D); addf((size_t)L * 512); addf((size_t)L * D); addf((size_t)L * D);
     for (int i = 0; i < 4; ++i) addf((size_t)L * 512);
@@ -402,7 +401,8 @@ int lg_engine_finalize_weights(lg_engine* e) {
     const size_t cat_layer = (size_t)512 * 512 * es * planes, w2_layer = (size_t)256 * 512 * es * planes;
     for (int i = 0; i < 2; ++i) { total = ((total + 255) & ~size_t(255)) + L * cat_layer; total = ((total + 255) & ~size_t(255)) + L * w2_layer; }
     const size_t sqkv_layer = (size_t)768 * 256 * es * planes, cqkv_layer = (size_t)512 * 256 * es * planes;
-    total = ((total + 255) & ~size_t(255)) + L * sqkv_layer; total = ((total + 255) & ~size_t(255)) + L * cqkv_layer;
+    const size_t final_layer = (size_t)256 * 256 * es * planes;
+    total = ((total + 255) & ~size_t(255)) + L * sqkv_layer; total = ((total + 255) & ~size_t(255)) + L * cqkv_layer; total = ((total + 255) & ~size_t(255)) + L * final_layer;
     addf((size_t)L * 512); addf((size_t)L * 512);
     total += 4096;
     HIPCHK(hipDeviceSynchronize());   // weights may be in use by forwards still running on any stream
@@ -415,7 +415,6 @@ int lg_engine_finalize_weights(lg_engine* e) {
     takew(e->w_in, (size_t)D * Din);
     takew(e->w_sout, (size_t)L * D * D); takew(e->w_sf1, (size_t)L * 512 * 512); takew(e->w_sf2, (size_t)L * D * 512);
     takew(e->w_cout, (size_t)L * D * D); takew(e->w_cf1, (size_t)L * 512 * 512); takew(e->w_cf2, (size_t)L * D * 512);
-    takew(e->w_final, (size_t)L * D * D);
     e->b_in = takef(D); e->b_sqkv = takef((size_t)L * 768); e->b_sout = takef((size_t)L * D); e->b_sf1 = takef((size_t)L * 512); e->b_sf2 = takef((size_t)L * D);
     e->b_cqkv = takef((size_t)L * 512); e->b_cout = takef((size_t)L * D); e->b_cf1 = takef((size_t)L * 512); e->b_cf2 = takef((size_t)L * D); e->b_final = takef((size_t)L * D);
     e->ln_s_g = takef((size_t)L * 512); e->ln_s_b = takef((size_t)L * 512); e->ln_c_g = takef((size_t)L * 512); e->ln_c_b = takef((size_t)L * 512);
@@ -426,6 +425,8 @@ int lg_engine_finalize_weights(lg_engine* e) {
     e->b_scat = takef((size_t)L * 512); e->b_ccat = takef((size_t)L * 512);
     e->sqkv_layer_bytes = sqkv_layer; e->cqkv_layer_bytes = cqkv_layer;
     e->w_sqkv_p = static_cast<char*>(ar.take(L * sqkv_layer)); e->w_cqkv_p = static_cast<char*>(ar.take(L * cqkv_layer));
+    e->final_layer_bytes = final_layer; e->w_final_p = static_cast<char*>(ar.take(L * final_layer));
+    if (ar.used > total) return fail(LG_ERR_STATE, "weight arena carve overflow");
 
     std::string err;
     auto up_f32 = [&](float* dst, const float* src, size_t n) -> int { HIPCHK(hipMemcpy(dst, src, n * 4, hipMemcpyHostToDevice)); return LG_OK; };
@@ -512,7 +513,7 @@ int lg_engine_finalize_weights(lg_engine* e) {
             const std::string a = "log_assignment." + std::to_string(i) + ".";
             NEED(wf, a + "final_proj.weight", D, D); NEED(bf, a + "final_proj.bias", D);
             NEED(wm, a + "matchability.weight", 1, D); NEED(bm, a + "matchability.bias", 1);
-            TRY(upload_packed(prec, wf->data.data(), (size_t)D * D, e->w_final, (size_t)i * D * D));
+            TRY(upload_fragment_packed(prec, std::vector<double>(wf->data.begin(), wf->data.end()), D, D, e->w_final_p + (size_t)i * final_layer));
             TRY(up_f32(e->b_final + (size_t)i * D, bf->data.data(), D));
             TRY(up_f32(e->w_match + (size_t)i * D, wm->data.data(), D));
             TRY(up_f32(e->b_match + i, bm->data.data(), 1));
@@ -783,7 +784,14 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
     const bool fuse_next = e->fused_next && e->fused_tail && (e->tail_timing == 0 || e->tail_timing == 5 || e->tail_timing == 6) &&
                            e->debug_stop < 0 && launch_tail_supports_next(prec, ap);
     const bool prune_possible = do_prune && (n0 > e->cfg.pruning_min_kpts || n1 > e->cfg.pruning_min_kpts);
-    bool proj_done = false;
+    bool proj_done = false, final_done = false;
+    auto make_final = [&](const RowSpace& rs, int layer, bool per_pair) {   // final projection (ref :289-291: / d**0.25), lg_proj.hip / fused into the last tail
+        FinalArgs f{};
+        f.rs = rs; f.X = e->X; f.R = R; f.out = e->MD; f.scale = 0.25f;
+        f.W = e->w_final_p + (per_pair ? 0 : (size_t)layer * e->final_layer_bytes); f.bias = e->b_final + (per_pair ? 0 : (size_t)layer * D);
+        f.layer_of_pair = per_pair ? e->FINAL_LAYER : nullptr; f.w_layer_bytes = (long long)e->final_layer_bytes;
+        return f;
+    };
     for (int i = 0; i < L; ++i) {
         for (int blk = 0; blk < 2; ++blk) {  // 0 = SelfBlock (ref :159-172), 1 = CrossBlock (ref :201-230)
             if (!proj_done) {   // otherwise the previous block's tail kernel has already produced q/k/v (fused_next)
@@ -813,12 +821,19 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 ta.gamma = (blk ? e->ln_c_g : e->ln_s_g) + (size_t)i * 512; ta.beta = (blk ? e->ln_c_b : e->ln_s_b) + (size_t)i * 512;
                 ta.W2 = (blk ? e->w_ctail_2 : e->w_stail_2) + (size_t)i * e->tail_2_layer_bytes;
                 ta.b2 = (blk ? e->b_cf2 : e->b_sf2) + (size_t)i * D;
-                if (blk == 1 && i + 1 < L) {   // token confidence / matchability of layer i on the rows this CrossBlock tail produces (ref :548, :553)
-                    const bool prune_here = do_prune && prune_possible;
-                    if (do_stop) { ta.head_w0 = e->w_tok + (size_t)i * D; ta.head_b0 = e->b_tok + i; ta.head_out0 = e->CONF; }
-                    if (prune_here) {
-                        if (do_stop) { ta.head_w1 = e->w_match + (size_t)i * D; ta.head_b1 = e->b_match + i; ta.head_out1 = e->MSCORE; }
-                        else { ta.head_w0 = e->w_match + (size_t)i * D; ta.head_b0 = e->b_match + i; ta.head_out0 = e->MSCORE; }
+                if (blk == 1) {   // 256 -> 1 heads on the rows this CrossBlock tail produces
+                    // token confidence of layer i (ref :548) for the stop decision; matchability of layer i (ref :298-299): its sigmoid for
+                    // the pruning mask (ref :553) and its log-sigmoids as the assignment's matchability terms (ref :268-276) wherever a pair
+                    // may END at this layer — the last one, or any one with early stopping
+                    const bool last = i + 1 == L;
+                    const bool prune_here = !last && do_prune && prune_possible;
+                    const bool want_tok = !last && do_stop, want_ls = last || do_stop;
+                    if (want_tok) { ta.head_w0 = e->w_tok + (size_t)i * D; ta.head_b0 = e->b_tok + i; ta.head_out0 = e->CONF; }
+                    if (prune_here || want_ls) {
+                        float* sig = prune_here ? e->MSCORE : nullptr; float* ls = want_ls ? e->LS : nullptr;
+                        float* lsneg = (want_ls && io->log_assignment) ? e->LSNEG : nullptr;
+                        if (want_tok) { ta.head_w1 = e->w_match + (size_t)i * D; ta.head_b1 = e->b_match + i; ta.head_out1 = sig; ta.head_ls1 = ls; ta.head_lsneg1 = lsneg; }
+                        else { ta.head_w0 = e->w_match + (size_t)i * D; ta.head_b0 = e->b_match + i; ta.head_out0 = sig; ta.head_ls0 = ls; ta.head_lsneg0 = lsneg; }
                     }
                 }
                 ta.dbg = (e->tail_timing == 1 || (i == 0 && ((e->tail_timing == 5 && blk == 1) || (e->tail_timing == 6 && blk == 0)))) ? e->TAILDBG : nullptr;
@@ -830,6 +845,10 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                     ta.next = blk == 0 ? make_proj(i, 1) : make_proj(i + 1, 0);
                     if (ta.dbg && e->tail_timing >= 5) ta.next.dbg = e->TAILDBG2;
                     proj_done = true;
+                } else if (fuse_next && blk == 1 && i + 1 == L && !do_stop) {
+                    // fixed depth: every live pair ends here, so the LAST tail also runs the final projection of the log assignment on its x tile
+                    ta.fin = make_final(rs_act, L - 1, false);
+                    final_done = true;
                 }
                 TRY(prof_begin(e, PC_TAIL, s));
                 HIPCHK(launch_tail(prec, ap, ta, s));
@@ -911,18 +930,20 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
     }
     // ---- log assignment with the weights of the layer each pair stopped at (ref :591)
     {
-        RowDotArgs rd{};
-        rd.rs = rs_all; rd.X = e->X; rd.w0 = e->w_match; rd.b0 = e->b_match; rd.out0 = e->LS; rd.act0 = 2;
-        rd.layer_of_pair = e->FINAL_LAYER; rd.w_layer_stride = D; rd.ignore_active = 1;
-        if (io->log_assignment) { rd.w1 = e->w_match; rd.b1 = e->b_match; rd.out1 = e->MSCORE; rd.act1 = 3; }  // dustbin terms
-        TRY(prof_begin(e, PC_ROWDOT, s));
-        HIPCHK(launch_rowdot(rd, s));
-        TRY(prof_end(e, s));
-        GemmArgs g = gemm(EPI_STORE, rs_all, e->X, D, nullptr, 0, D, D, e->w_final, e->b_final, D, e->MD, D, 0.25f);  // ref :291: / d**0.25
-        g.layer_of_pair = e->FINAL_LAYER; g.w_layer_stride = (long long)D * D; g.b_layer_stride = D;
-        TRY(prof_begin(e, PC_GEMM_FINAL, s));
-        HIPCHK(launch_gemm(prec, EPI_STORE, g, s));
-        TRY(prof_end(e, s));
+        if (!e->fused_tail) {   // per-op path: matchability terms as their own pass (the fused CrossBlock tails emit them from their heads)
+            RowDotArgs rd{};
+            rd.rs = rs_all; rd.X = e->X; rd.w0 = e->w_match; rd.b0 = e->b_match; rd.out0 = e->LS; rd.act0 = 2;
+            rd.layer_of_pair = e->FINAL_LAYER; rd.w_layer_stride = D; rd.ignore_active = 1;
+            if (io->log_assignment) { rd.w1 = e->w_match; rd.b1 = e->b_match; rd.out1 = e->LSNEG; rd.act1 = 3; }  // dustbin terms
+            TRY(prof_begin(e, PC_ROWDOT, s));
+            HIPCHK(launch_rowdot(rd, s));
+            TRY(prof_end(e, s));
+        }
+        if (!final_done) {
+            TRY(prof_begin(e, PC_GEMM_FINAL, s));
+            HIPCHK(launch_final_proj(prec, make_final(rs_all, 0, true), s));
+            TRY(prof_end(e, s));
+        }
         SimArgs sm{rs_all, e->MD, D, D, e->SIM};
         TRY(prof_begin(e, PC_SIM, s));
         HIPCHK(launch_sim(prec, sm, s));
@@ -932,7 +953,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
         as.max1 = e->MAX1; as.arg1 = e->ARG1; as.cpm = e->CPM; as.cps = e->CPS; as.cbv = e->CBV; as.cbi = e->CBI; as.ind = e->IND; as.n0 = n0; as.n1 = n1; as.filter_threshold = (float)e->cfg.filter_threshold;
         as.m0 = io->matches0; as.m1 = io->matches1; as.s0 = io->scores0; as.s1 = io->scores1;
         as.matches = io->matches; as.mscores = io->match_scores; as.n_matches = io->n_matches; as.max_matches = max_matches;
-        as.log_assignment = io->log_assignment; as.lsneg = e->MSCORE;
+        as.log_assignment = io->log_assignment; as.lsneg = e->LSNEG;
         as.dbg = e->tail_timing == 4 ? e->TAILDBG : nullptr;
         as.all_rows_live = (!do_prune && !io->num0 && !io->num1) ? 1 : 0;
         TRY(prof_begin(e, PC_ASSIGN, s));

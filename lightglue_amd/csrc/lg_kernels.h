@@ -51,6 +51,20 @@ struct ProjArgs {
 };
 hipError_t launch_proj(int prec, int attn_prec, const ProjArgs& a, hipStream_t s);
 
+// ---------------------------------------------------------------- final projection (lg_proj.hip; ref lightglue.py:289-291)
+// MD[row, :] = (final_proj(x[row]) ) / 256^0.25 with the weights of the layer each pair stopped at: the same workgroup shape and operand
+// scheme as the attention projections (64 rows x all 256 columns, weights fragment-packed like TailArgs), as its own launch (adaptive
+// depth: per-pair layer select) or run by the LAST tail kernel on the x tile it has just produced (TailArgs::fin, fixed depth).
+struct FinalArgs {
+    RowSpace rs;
+    const float* X;
+    const void* W; const float* bias;               // [layers][256][256] fragment-packed (hi plane then lo plane per layer), [layers][256]
+    const int* layer_of_pair; long long w_layer_bytes;   // optional per-pair layer select; nullptr: W / bias point at the layer to use
+    float* out; float scale;                         // [R][256] fp32
+    int R;
+};
+hipError_t launch_final_proj(int prec, const FinalArgs& a, hipStream_t s);
+
 // ---------------------------------------------------------------- fused block tail (lg_tail.hip)
 // x <- x + ffn(cat[x, out_proj(ctx)]) with out_proj folded into ffn.0 on the host (see lg_tail.hip).
 // Weights are packed in MFMA-fragment order: plane p (hi, lo) at element offset p*rows*512, and within a
@@ -68,9 +82,16 @@ struct TailArgs {
     // adaptive path; the dot products are reduced in a fixed order (lane values, the 4 lane groups, the 8 waves).
     const float* head_w0; const float* head_b0; float* head_out0;
     const float* head_w1; const float* head_b1; float* head_out1;
+    // further outputs of the same logits (nullptr = off): logsigmoid(z) and logsigmoid(-z) — the matchability terms of the log assignment
+    // (ref :268-276) for the layer a pair ENDS at: written by every CrossBlock tail a pair may end after, so the last write a pair's rows
+    // receive is the one of its final layer (replaces the rowdot launch in front of the assignment).  head_out* may be nullptr then.
+    float* head_ls0; float* head_lsneg0;
+    float* head_ls1; float* head_lsneg1;
     // optional: the NEXT block's q/k/v projection, run on the x tile this kernel has just produced (next.W == nullptr:
     // none).  next.X is unused; supported for 16-bit operand / attention precisions (launch_tail_supports_next).
     ProjArgs next;
+    // optional (fin.W != nullptr, instead of `next`): the final projection of the log assignment on the x tile of the LAST block
+    FinalArgs fin;
 };
 bool launch_tail_supports_next(int prec, int attn_prec);
 hipError_t launch_tail(int prec, int attn_prec, const TailArgs& a, hipStream_t s);    // 8 waves, one workgroup per CU (lg_tail.hip)

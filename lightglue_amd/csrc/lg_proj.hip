@@ -13,12 +13,40 @@
 
 namespace lg {
 
-template <int PREC, class TA, int NTP, int NPASS>
-__global__ __launch_bounds__(PTHREADS) void proj_kernel(ProjArgs a) {
+// activation tile: HBM -> registers -> operand precision -> LDS (once); no barrier (proj_compute / final_compute synchronise)
+template <int PREC>
+__device__ __forceinline__ void proj_load_tile(const float* X, const TileLoc& t, char* smA) {
     typedef typename PJ<PREC>::Tag Tag;
     constexpr int EPC = Tag::EPC;
     constexpr int KE = PJL<PREC>::KE, STAGES = PJL<PREC>::STAGES, TILE = PJL<PREC>::TILE, A_PLANE = PJL<PREC>::A_PLANE;
     constexpr int NV = EPC / 4;
+    const int tid = threadIdx.x;
+    const int srow = tid >> 3, sslot = tid & 7;
+    const float* src = X + (long long)(t.grow0 + srow) * 256 + sslot * EPC;
+    f32x4 hreg[STAGES][NV];
+#pragma unroll
+    for (int st = 0; st < STAGES; ++st)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) hreg[st][j] = *reinterpret_cast<const f32x4*>(src + st * KE + 4 * j);
+    const int off = pj_tile_off(srow, sslot);
+#pragma unroll
+    for (int st = 0; st < STAGES; ++st) {
+        char* tile = smA + st * TILE;
+        if constexpr (PREC == PREC_F32) {
+            *reinterpret_cast<f32x4*>(tile + off) = hreg[st][0];
+        } else if constexpr (PJ<PREC>::APART == 2) {
+            u32x4 hi, lo;
+            split8<Tag>(hreg[st][0], hreg[st][1], hi, lo);
+            *reinterpret_cast<u32x4*>(tile + off) = hi;
+            *reinterpret_cast<u32x4*>(tile + A_PLANE + off) = lo;
+        } else {   // single plane (PREC_QKV_F16W2: one f16 plane)
+            *reinterpret_cast<u32x4*>(tile + off) = pack8<Tag>(hreg[st][0], hreg[st][1]);
+        }
+    }
+}
+
+template <int PREC, class TA, int NTP, int NPASS>
+__global__ __launch_bounds__(PTHREADS) void proj_kernel(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* smA = smem;                                              // [NPART][STAGES][64][128 B]
 
@@ -27,33 +55,43 @@ __global__ __launch_bounds__(PTHREADS) void proj_kernel(ProjArgs a) {
     if (a.rs.active && !a.rs.active[t.pair]) return;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8] = clock64();   // profiling tap, slot 0
-
-    // ---- activation tile: HBM -> registers -> operand precision -> LDS (once)
-    {
-        const int srow = tid >> 3, sslot = tid & 7;
-        const float* src = a.X + (long long)(t.grow0 + srow) * 256 + sslot * EPC;
-        f32x4 hreg[STAGES][NV];
-#pragma unroll
-        for (int st = 0; st < STAGES; ++st)
-#pragma unroll
-            for (int j = 0; j < NV; ++j) hreg[st][j] = *reinterpret_cast<const f32x4*>(src + st * KE + 4 * j);
-        const int off = pj_tile_off(srow, sslot);
-#pragma unroll
-        for (int st = 0; st < STAGES; ++st) {
-            char* tile = smA + st * TILE;
-            if constexpr (PREC == PREC_F32) {
-                *reinterpret_cast<f32x4*>(tile + off) = hreg[st][0];
-            } else if constexpr (PJ<PREC>::APART == 2) {
-                u32x4 hi, lo;
-                split8<Tag>(hreg[st][0], hreg[st][1], hi, lo);
-                *reinterpret_cast<u32x4*>(tile + off) = hi;
-                *reinterpret_cast<u32x4*>(tile + A_PLANE + off) = lo;
-            } else {   // single plane (PREC_QKV_F16W2: one f16 plane)
-                *reinterpret_cast<u32x4*>(tile + off) = pack8<Tag>(hreg[st][0], hreg[st][1]);
-            }
-        }
-    }
+#ifdef LG_PROJ_ROPE_ONCE
+    RopeRows<4> rr;
+    if constexpr (NTP == 3) proj_rope_load<4>(a, t, rr);
+    proj_load_tile<PREC>(a.X, t, smA);
+    proj_compute<PREC, TA, NTP, NPASS>(a, t, smA, 0, NTP == 3 ? &rr : nullptr);
+#else
+    proj_load_tile<PREC>(a.X, t, smA);
     proj_compute<PREC, TA, NTP, NPASS>(a, t, smA, 0);
+#endif
+}
+
+// final projection of the log assignment as its own launch (adaptive depth: the weights of the layer each pair stopped at)
+template <int PREC>
+__global__ __launch_bounds__(PTHREADS) void final_proj_kernel(FinalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const TileLoc t = locate_tile(a.rs, blockIdx.x, PBM);
+    if (t.r0 >= a.rs.len[t.seg]) return;
+    if (a.rs.active && !a.rs.active[t.pair]) return;
+    proj_load_tile<PREC>(a.X, t, smem);
+    final_compute<PREC>(a, t, smem);
+}
+template <int PREC> static hipError_t launch_final_t(const FinalArgs& a, hipStream_t s) {
+    constexpr int smem = PJL<PREC>::A_BYTES;
+    auto kern = final_proj_kernel<PREC>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(a.R / PBM), dim3(PTHREADS), smem, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_final_proj(int prec, const FinalArgs& a, hipStream_t s) {
+    switch (prec) {
+        case PREC_F32: return launch_final_t<PREC_F32>(a, s);
+        case PREC_BF16: return launch_final_t<PREC_BF16>(a, s);
+        case PREC_F16: return launch_final_t<PREC_F16>(a, s);
+        case PREC_F16X3: return launch_final_t<PREC_F16X3>(a, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 template <int PREC, class TA, int NTP, int NPASS> static hipError_t launch_proj_t(const ProjArgs& a, hipStream_t s) {

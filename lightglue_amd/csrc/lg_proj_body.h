@@ -84,9 +84,22 @@ template <int NTP> __device__ __forceinline__ int pj_tile(int w, int pass, int j
 //     -> one 16-byte store per plane into the transposed [head][64][R] layout (8 consecutive rows of one channel).
 // Nothing is staged through LDS and no barrier follows the MFMA loop (the staged version spent 40 % of the kernel in its two
 // epilogues: LDS write, barrier, LDS read, store, barrier).
+// the rotary rows of the tile (cos, sin: one float4 per 16-row tile and lane): the same 32 values for the q pass and the k pass
+template <int MT> struct RopeRows { f32x4 c[MT], s[MT]; };
+template <int MT>
+__device__ __forceinline__ void proj_rope_load(const ProjArgs& a, const TileLoc& t, RopeRows<MT>& rr) {
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, g = lane >> 4;
+    const int pcol = 32 * w;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const long long row = t.grow0 + pj_row<MT>(mt, lr);
+        rr.c[mt] = *reinterpret_cast<const f32x4*>(a.cosb + row * 32 + ((pcol & 63) >> 1) + 4 * g);
+        rr.s[mt] = *reinterpret_cast<const f32x4*>(a.sinb + row * 32 + ((pcol & 63) >> 1) + 4 * g);
+    }
+}
 template <int PREC, class TA, int NTP, int NPASS, int PASS, int A_PLANE, int MT>
 __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, const char* smA, u32x4 (&bf)[PJ<PREC>::NPART == 2 ? 2 : 4][NTP][PJ<PREC>::NPART],
-                                          int stamp_base) {
+                                          int stamp_base, const RopeRows<MT>& rr) {
     typedef typename PJ<PREC>::Tag Tag;
     constexpr int NPART = PJ<PREC>::NPART, APART = PJ<PREC>::APART;
     constexpr int STAGES = PJL<PREC>::STAGES, NKC = 2 * STAGES, TILE = MT * 16 * 128;   // one plane of one K stage: MT*16 rows x 128 B
@@ -156,12 +169,17 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
     if constexpr (HAS_PAIR) {
         pb[0] = *reinterpret_cast<const f32x4*>(a.bias + pcol + 8 * g); pb[1] = *reinterpret_cast<const f32x4*>(a.bias + pcol + 8 * g + 4);
         if constexpr (ROPE) {
+#ifdef LG_PROJ_ROPE_ONCE
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { pc[mt] = rr.c[mt]; ps[mt] = rr.s[mt]; }
+#else
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const long long row = t.grow0 + pj_row<MT>(mt, lr);
                 pc[mt] = *reinterpret_cast<const f32x4*>(a.cosb + row * 32 + ((pcol & 63) >> 1) + 4 * g);
                 ps[mt] = *reinterpret_cast<const f32x4*>(a.sinb + row * 32 + ((pcol & 63) >> 1) + 4 * g);
             }
+#endif
         }
     }
 #pragma unroll
@@ -238,7 +256,7 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
 // NTP = n-tiles per wave per pass: self (768 columns) 3 x 2 passes, cross (512 columns) 2 x 2.  A_PLANE = byte distance
 // between the hi and lo planes of the activation tile in LDS; MT = 16-row tiles of the workgroup's row tile (4 or 8).
 template <int PREC, class TA, int NTP, int NPASS, int A_PLANE = PJL<PREC>::A_PLANE, int MT = 4>
-__device__ __forceinline__ void proj_compute(const ProjArgs& a, const TileLoc& t, const char* smA, int stamp_base) {
+__device__ __forceinline__ void proj_compute(const ProjArgs& a, const TileLoc& t, const char* smA, int stamp_base, const RopeRows<MT>* preloaded = nullptr) {
     static_assert(NPASS == 2, "two passes");
     typedef typename PJ<PREC>::Tag Tag;
     constexpr int NPART = PJ<PREC>::NPART;
@@ -255,10 +273,80 @@ __device__ __forceinline__ void proj_compute(const ProjArgs& a, const TileLoc& t
                 const char* ptr = static_cast<const char*>(a.W) + (p ? (long long)a.Nout * 256 * (long long)sizeof(typename Tag::elem) : 0);
                 bf[i][j][p] = *reinterpret_cast<const u32x4*>(ptr + ((long long)(pj_tile<NTP>(w, 0, j) * NKC + i) * 64 + lane) * 16);
             }
+    RopeRows<MT> rr;
+#ifdef LG_PROJ_ROPE_ONCE
+    // experiment: the rotary rows are fetched ONCE (both passes rotate by the same rows) and AHEAD of the MFMA loops — behind the first weight
+    // fragments in the in-order load queue; the standalone kernel requests them before its x tile (both cold, in flight together)
+    if constexpr (NTP == 3) { if (preloaded) rr = *preloaded; else proj_rope_load<MT>(a, t, rr); }
+#endif
     __syncthreads();   // the activation tile is complete
     if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8 + stamp_base + 1] = clock64();
-    proj_pass<PREC, TA, NTP, NPASS, 0, A_PLANE, MT>(a, t, smA, bf, stamp_base);
-    proj_pass<PREC, TA, NTP, NPASS, 1, A_PLANE, MT>(a, t, smA, bf, stamp_base);
+    proj_pass<PREC, TA, NTP, NPASS, 0, A_PLANE, MT>(a, t, smA, bf, stamp_base, rr);
+    proj_pass<PREC, TA, NTP, NPASS, 1, A_PLANE, MT>(a, t, smA, bf, stamp_base, rr);
+}
+
+// The final projection of the log assignment (ref :289-291) on a 64 x 256 activation tile in LDS (same layout and precondition as
+// proj_compute): 256 output columns = 16 n-tiles, wave w owns tiles 2w, 2w + 1 = columns [32w, 32w + 32); TRANSPOSED form, so lane
+// (lr, g) ends with keypoint row pj_row(mt, lr) and 4 consecutive columns per tile: one 16-byte fp32 store each, 64 contiguous bytes
+// per row over g.  One pass, weight ring 3 chunks ahead (16 VGPRs per chunk).  Used by the standalone kernel (lg_proj.hip) and by the
+// last tail (lg_tail.hip, NEXT == 3): the same arithmetic on the same operand planes, so both give bit-identical rows.
+template <int PREC, int A_PLANE = PJL<PREC>::A_PLANE, int MT = 4>
+__device__ __forceinline__ void final_compute(const FinalArgs& a, const TileLoc& t, const char* smA) {
+    typedef typename PJ<PREC>::Tag Tag;
+    constexpr int NPART = PJ<PREC>::NPART, APART = PJ<PREC>::APART;
+    constexpr int STAGES = PJL<PREC>::STAGES, NKC = 2 * STAGES, TILE = MT * 16 * 128;
+    constexpr int NBUF = 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, g = lane >> 4;
+    const int layer = a.layer_of_pair ? a.layer_of_pair[t.pair] : 0;
+    const char* W = static_cast<const char*>(a.W) + (long long)layer * a.w_layer_bytes;
+    const float* bias = a.bias + (long long)layer * 256;
+    auto wfrag = [&](int p, int nt, int kc) -> u32x4 {
+        const char* ptr = W + (p ? 256LL * 256 * (long long)sizeof(typename Tag::elem) : 0);
+        return *reinterpret_cast<const u32x4*>(ptr + ((long long)(nt * NKC + kc) * 64 + lane) * 16);
+    };
+    auto load_b = [&](u32x4 (&dst)[2][NPART], int kc) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p = 0; p < NPART; ++p) dst[j][p] = wfrag(p, 2 * w + j, kc);
+    };
+    u32x4 bf[NBUF][2][NPART];
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) load_b(bf[i], i);
+    f32x4 b4[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b4[j] = *reinterpret_cast<const f32x4*>(bias + (2 * w + j) * 16 + 4 * g);
+    __syncthreads();   // the activation tile is complete
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+    for (int c0 = 0; c0 < NKC; c0 += NBUF) {
+#pragma unroll
+        for (int i = 0; i < NBUF; ++i) {
+            const int kc = c0 + i;
+            load_b(bf[(i + NBUF - 1) % NBUF], kc + NBUF - 1 < NKC ? kc + NBUF - 1 : NKC - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const char* tile = smA + (kc >> 1) * TILE;
+            u32x4 af[MT][APART];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int p = 0; p < APART; ++p)
+                    af[mt][p] = *reinterpret_cast<const u32x4*>(tile + p * A_PLANE + pj_tile_off(pj_row<MT>(mt, lr), (kc & 1) * 4 + g));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) pj_mma<PREC, true>(acc[mt][j], bf[i][j], af[mt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        float* dst = a.out + (t.grow0 + pj_row<MT>(mt, lr)) * 256LL + 32 * w + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(dst + 16 * j) = (acc[mt][j] + b4[j]) * a.scale;
+    }
 }
 
 }  // namespace lg

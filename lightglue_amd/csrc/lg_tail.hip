@@ -98,7 +98,7 @@ __device__ __forceinline__ void tail_mma(f32x4& acc, const u32x4* wf, const u32x
 }
 
 // NEXT: 0 = plain tail, 1 = + SelfBlock projection of the next layer (768 columns, rotary), 2 = + CrossBlock
-// projection (512 columns).  TA = element type of q/k/v (attention operand precision), only read when NEXT != 0.
+// projection (512 columns), 3 = + the final projection of the log assignment (256 columns, fp32 out; the last block of a fixed-depth forward).  TA = element type of q/k/v (attention operand precision), only read when NEXT != 0.
 // MT = 16-row tiles per workgroup: 4 (64 rows, the throughput shape) or 2 / 1 for under-filled grids (small batches): the
 // same per-row arithmetic in the same order — outputs are bit-identical — on 2x / 4x as many workgroups; each of them streams
 // the full weight set, so these shapes are L2-stream-bound per CU (~46k cycles) instead of matrix-bound.
@@ -157,13 +157,13 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     constexpr int HS = STAGES / 2;                    // stage tiles per half (4, or 8 for f32)
     constexpr int SPR = 4 / MT, ROUNDS = HS / SPR;    // stage tiles per round, rounds per half
     const int srow = (tid >> 3) & (TBM - 1), sslot = tid & 7, sst = tid / (128 * MT);
-    f32x4 hreg[ROUNDS][NV];
+    f32x4 hregs[2][ROUNDS][NV];   // [0] x rows, [1] ctx rows
     auto load_half = [&](int hf) {
         const float* src = (hf ? a.CTX : a.X) + (long long)(t.grow0 + srow) * 256 + sslot * EPC;
 #pragma unroll
         for (int i = 0; i < ROUNDS; ++i)
 #pragma unroll
-            for (int j = 0; j < NV; ++j) hreg[i][j] = *reinterpret_cast<const f32x4*>(src + (i * SPR + sst) * KE + 4 * j);
+            for (int j = 0; j < NV; ++j) hregs[hf][i][j] = *reinterpret_cast<const f32x4*>(src + (i * SPR + sst) * KE + 4 * j);
     };
     auto store_half = [&](int hf) {
         const int off = lds_off<128>(srow, sslot);
@@ -171,14 +171,14 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         for (int i = 0; i < ROUNDS; ++i) {
             char* tile = smem + (hf * HS + i * SPR + sst) * TILE;   // planes: p * G_PLANE
             if constexpr (PREC == PREC_F32) {
-                *reinterpret_cast<f32x4*>(tile + off) = hreg[i][0];
+                *reinterpret_cast<f32x4*>(tile + off) = hregs[hf][i][0];
             } else if constexpr (NPART == 2) {
                 u32x4 hi, lo;
-                split8<Tag>(hreg[i][0], hreg[i][1], hi, lo);
+                split8<Tag>(hregs[hf][i][0], hregs[hf][i][1], hi, lo);
                 *reinterpret_cast<u32x4*>(tile + off) = hi;
                 *reinterpret_cast<u32x4*>(tile + G_PLANE + off) = lo;
             } else {
-                *reinterpret_cast<u32x4*>(tile + off) = pack8<Tag>(hreg[i][0], hreg[i][1]);
+                *reinterpret_cast<u32x4*>(tile + off) = pack8<Tag>(hregs[hf][i][0], hregs[hf][i][1]);
             }
         }
     };
@@ -210,11 +210,18 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             for (int nt = 0; nt < 4; ++nt) tail_mma<PREC>(acc[mt][nt], b[nt], af[mt]);
     };
     load_half(0);
+#ifdef LG_TAIL_EARLY_CTX   // experiment: the ctx rows are requested right behind the x rows (they were requested after the first barrier: the
+    // counter being in order, chunk 1's weight fragments — issued behind them — then waited out the whole cold 64 KB ctx load)
+    load_half(1);
+#endif
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i) load_b_A(bf[i], i);
+    __builtin_amdgcn_sched_barrier(0);
     store_half(0);
     __syncthreads();
+#ifndef LG_TAIL_EARLY_CTX
     load_half(1);                       // ctx rows stream in while the x half is multiplied
+#endif
     __builtin_amdgcn_sched_barrier(0);
     constexpr int HC = NKC / 2;         // k-chunks per half
     // The activation fragments of chunk kc + 1 are read from LDS BEFORE the MFMAs of chunk kc (two register sets): with
@@ -238,6 +245,15 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             }
         }
         if (hf == 0) {
+#ifndef LG_TAIL_NO_LAUNDER
+            // the ctx rows' conversion must stay HERE: without the laundering hipcc hoists the pure split arithmetic of store_half(1) to right
+            // behind the loads (16 packed registers instead of 32 through the loop) — and waits for the cold ctx loads BEFORE the first MFMA
+            // (vmcnt(6) .. vmcnt(0) in front of the loop, seen in the ISA in round 4: the whole ctx round trip exposed in every workgroup)
+#pragma unroll
+            for (int i = 0; i < ROUNDS; ++i)
+#pragma unroll
+                for (int j = 0; j < NV; ++j) asm volatile("" : "+v"(hregs[1][i][j]));
+#endif
             store_half(1);
             __syncthreads();
         }
@@ -293,9 +309,9 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     // ------------------------------------------------------------------ GELU + g -> LDS (B-operand tiles) + phase B
     // n-tile j of wave w = hidden units [(w + 8j)*16, +16) = K-stage 2j + (w >> 2), columns (w & 3)*16 + 4g + r of it:
     // a lane's 4 values are 4 consecutive k of one row = one 8-byte piece per plane (f32: one 16-byte piece).
-    auto gelu_store = [&](int j) {
+    auto gelu_store = [&](int j, int mt0 = 0, int mt1 = MT) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        for (int mt = mt0; mt < mt1; ++mt) {
             const f32x2 v01 = gelu_pair(f32x2{acc[mt][j][0], acc[mt][j][1]});
             const f32x2 v23 = gelu_pair(f32x2{acc[mt][j][2], acc[mt][j][3]});
             const int row = mt * 16 + lr;
@@ -340,6 +356,13 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             for (int nt = 0; nt < 2; ++nt) tail_mma<PREC>(acc2[mt][nt], b[nt], af[mt]);
     };
     load_b_B(b2f[0], 0); load_b_B(b2f[1], 1); load_b_B(b2f[2], 2);
+#ifdef LG_TAIL_ROPE_PF
+    // experiment: the fused SelfBlock projection opens each pass's epilogue with the rotary rows of this tile (64 rows x 128 B per table, cold:
+    // a full HBM round trip in front of the stores, twice per workgroup).  Touch every line now — behind the first W2 fragments in the in-order
+    // load queue, a whole GELU step before anything younger is waited for — so that the epilogues find them in L2.  No branch around the load.
+    float rope_pf = 0.f;
+    if constexpr (NEXT == 1) rope_pf = (((tid >> 6) & 1) ? a.next.sinb : a.next.cosb)[(long long)(t.grow0 + (tid & 63)) * 32 + (tid >> 7) * 8];
+#endif
     gelu_store(0);
     __syncthreads();
     stamp(3);
@@ -361,22 +384,40 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
                     xres[mt][nt] = *reinterpret_cast<const f32x4*>(a.X + (long long)(t.grow0 + mt * 16 + lr) * 256 + w * 32 + nt * 16 + 4 * g);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) b2v[nt] = *reinterpret_cast<const f32x4*>(a.b2 + w * 32 + nt * 16 + 4 * g);
-            if (heads) {
+            {   // NOT branched around (a conditional load makes hipcc wait vmcnt(0) at the join — here: for the residual rows just requested, in
+                // front of the last step's MFMAs, in every CrossBlock tail of the adaptive path): absent heads read the output bias instead
+                const float* w0p = heads ? a.head_w0 : a.b2;
+                const float* w1p = a.head_w1 ? a.head_w1 : a.b2;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    hw0[nt] = *reinterpret_cast<const f32x4*>(a.head_w0 + w * 32 + nt * 16 + 4 * g);
-                    if (a.head_w1) hw1[nt] = *reinterpret_cast<const f32x4*>(a.head_w1 + w * 32 + nt * 16 + 4 * g);
+                    hw0[nt] = *reinterpret_cast<const f32x4*>(w0p + w * 32 + nt * 16 + 4 * g);
+                    hw1[nt] = *reinterpret_cast<const f32x4*>(w1p + w * 32 + nt * 16 + 4 * g);
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < CPS; ++i) {
             const int kc = j * CPS + i;
-            load_b_B(b2f[(kc + 3) & 3], kc + 3 < NKC ? kc + 3 : NKC - 1);
+            // j and i are unrolled constants: a plain `if` is resolved at compile time (no join, no conservative wait)
+#ifdef LG_TAIL_PIN_B
+            // experiment: the ring pinned where the source puts it.  Left to itself hipcc issues a chunk's W2 fragments ~1 chunk (step 3: 0 - 7
+            // MFMAs) ahead of their MFMAs instead of 3 (round-4 ISA, tools/isa_wait_distance.py); sched_barrier masks that let the GELU arithmetic
+            // float did not hold the loads (the MFMAs moved instead), so the windows are closed and the GELU of the next n-tile is dealt to them
+            // by hand: row tile i of n-tile j + 1 next to the MFMAs of chunk i
+            __builtin_amdgcn_sched_barrier(0);
+            if (kc + 3 < NKC) load_b_B(b2f[(kc + 3) & 3], kc + 3);
+            __builtin_amdgcn_sched_barrier(0);
             chunk_B(kc, b2f[kc & 3]);
+            if (j < 3) gelu_store(j + 1, i * MT / CPS, (i + 1) * MT / CPS);
+#else
+            if (kc + 3 < NKC) load_b_B(b2f[(kc + 3) & 3], kc + 3);
+            chunk_B(kc, b2f[kc & 3]);
+#endif
         }
         if (j < 3) {
+#ifndef LG_TAIL_PIN_B
             gelu_store(j + 1);
+#endif
             __syncthreads();
         }
     }
@@ -403,7 +444,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             if constexpr (NEXT != 0) {
                 static_assert(EPC == 8, "fused next projection: 16-bit operands only");
                 char* dst = smem + (col >> 6) * TILE + pj_tile_off(row, (col & 63) >> 3) + (col & 7) * 2;   // the projection's own swizzle (lg_proj_body.h)
-                if constexpr (NPART == 2 && ASPLIT) {   // hi + lo planes of the new x tile (lo at G_PLANE: K-stages 0..3 of the lo g plane are just as dead)
+                if constexpr (NPART == 2 && (ASPLIT || NEXT == 3)) {   // hi + lo planes of the new x tile (the final projection always takes both) (lo at G_PLANE: K-stages 0..3 of the lo g plane are just as dead)
                     uint32_t h01, l01, h23, l23;
                     split2_f16(xn[0], xn[1], h01, l01); split2_f16(xn[2], xn[3], h23, l23);
                     *reinterpret_cast<u32x2*>(dst) = u32x2{h01, h23};
@@ -427,16 +468,25 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         if (tid < TBM && t.r0 + tid < qlen) {
             const f32x4* pr = reinterpret_cast<const f32x4*>(red2 + tid * 8);
             const f32x4 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
-            const float z0 = (((p0[0] + p0[2]) + (p1[0] + p1[2])) + ((p2[0] + p2[2]) + (p3[0] + p3[2]))) + a.head_b0[0];
-            a.head_out0[t.grow0 + tid] = 1.f / (1.f + expf(-z0));
-            if (a.head_w1) {
-                const float z1 = (((p0[1] + p0[3]) + (p1[1] + p1[3])) + ((p2[1] + p2[3]) + (p3[1] + p3[3]))) + a.head_b1[0];
-                a.head_out1[t.grow0 + tid] = 1.f / (1.f + expf(-z1));
-            }
+            // sigmoid for the adaptive decisions; logsigmoid(z) / logsigmoid(-z) = the matchability terms of the log assignment (ref :268-276)
+            auto emit = [&](float z, float* sig, float* ls, float* lsneg) {
+                if (sig) sig[t.grow0 + tid] = 1.f / (1.f + expf(-z));
+                if (ls || lsneg) {
+                    const float sp = log1pf(expf(-fabsf(z)));
+                    if (ls) ls[t.grow0 + tid] = fminf(z, 0.f) - sp;
+                    if (lsneg) lsneg[t.grow0 + tid] = fminf(-z, 0.f) - sp;
+                }
+            };
+            emit((((p0[0] + p0[2]) + (p1[0] + p1[2])) + ((p2[0] + p2[2]) + (p3[0] + p3[2]))) + a.head_b0[0], a.head_out0, a.head_ls0, a.head_lsneg0);
+            if (a.head_w1) emit((((p0[1] + p0[3]) + (p1[1] + p1[3])) + ((p2[1] + p2[3]) + (p3[1] + p3[3]))) + a.head_b1[0], a.head_out1, a.head_ls1, a.head_lsneg1);
         }
     }
     stamp(5);
-    if constexpr (NEXT != 0) proj_compute<(prec_is_split(PREC) ? (ASPLIT ? PREC_F16X3 : PREC_QKV_F16W2) : PREC), TA, NEXT == 1 ? 3 : 2, 2, G_PLANE, MT>(a.next, t, smem, 0);
+#ifdef LG_TAIL_ROPE_PF
+    asm volatile("" :: "v"(rope_pf));   // keeps the touch alive (and waits for it here at the latest)
+#endif
+    if constexpr (NEXT == 3) final_compute<PREC, G_PLANE, MT>(a.fin, t, smem);
+    else if constexpr (NEXT != 0) proj_compute<(prec_is_split(PREC) ? (ASPLIT ? PREC_F16X3 : PREC_QKV_F16W2) : PREC), TA, NEXT == 1 ? 3 : 2, 2, G_PLANE, MT>(a.next, t, smem, 0);
     if (a.dbg && lane == 0)   // wall clock at the end + where the workgroup ran (HW_ID, XCC_ID)
         a.dbg[((long long)blockIdx.x * 8 + w) * 8 + 7] = (wall_clock64() & ((1LL << 44) - 1)) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFF00) << 40) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 44);
 }
@@ -459,6 +509,7 @@ template <int PREC, int NEXT, class TA, bool ASPLIT> static hipError_t launch_ta
     }
 }
 template <int PREC, class TA, bool ASPLIT> static hipError_t launch_tail_next(const TailArgs& a, hipStream_t s) {
+    if (a.fin.W) return a.next.W ? hipErrorInvalidValue : launch_tail_t<PREC, 3, TA, false>(a, s);
     if (!a.next.W) return launch_tail_t<PREC, 0, TA, false>(a, s);
     if (ASPLIT && a.next.plane <= 0) return hipErrorInvalidValue;
     if (a.next.Nout == 768 && a.next.cosb) return launch_tail_t<PREC, 1, TA, ASPLIT>(a, s);
@@ -473,7 +524,7 @@ bool launch_tail_supports_next(int prec, int attn_prec) {
 }
 
 hipError_t launch_tail(int prec, int attn_prec, const TailArgs& a, hipStream_t s) {
-    if (a.next.W && !launch_tail_supports_next(prec, attn_prec)) return hipErrorInvalidValue;
+    if ((a.next.W || a.fin.W) && !launch_tail_supports_next(prec, attn_prec)) return hipErrorInvalidValue;
     switch (prec) {
         case PREC_F32: return launch_tail_t<PREC_F32, 0, float, false>(a, s);
         case PREC_BF16: return launch_tail_next<PREC_BF16, bf16_t, false>(a, s);

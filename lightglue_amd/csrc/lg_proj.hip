@@ -55,15 +55,10 @@ __global__ __launch_bounds__(PTHREADS) void proj_kernel(ProjArgs a) {
     if (a.rs.active && !a.rs.active[t.pair]) return;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8] = clock64();   // profiling tap, slot 0
-#ifdef LG_PROJ_ROPE_ONCE
     RopeRows<4> rr;
-    if constexpr (NTP == 3) proj_rope_load<4>(a, t, rr);
+    if constexpr (NTP == 3) proj_rope_load<4>(a, t, rr);   // before the x tile: both are cold, in flight together
     proj_load_tile<PREC>(a.X, t, smA);
     proj_compute<PREC, TA, NTP, NPASS>(a, t, smA, 0, NTP == 3 ? &rr : nullptr);
-#else
-    proj_load_tile<PREC>(a.X, t, smA);
-    proj_compute<PREC, TA, NTP, NPASS>(a, t, smA, 0);
-#endif
 }
 
 // final projection of the log assignment as its own launch (adaptive depth: the weights of the layer each pair stopped at)

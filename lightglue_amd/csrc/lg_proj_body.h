@@ -169,17 +169,8 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
     if constexpr (HAS_PAIR) {
         pb[0] = *reinterpret_cast<const f32x4*>(a.bias + pcol + 8 * g); pb[1] = *reinterpret_cast<const f32x4*>(a.bias + pcol + 8 * g + 4);
         if constexpr (ROPE) {
-#ifdef LG_PROJ_ROPE_ONCE
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { pc[mt] = rr.c[mt]; ps[mt] = rr.s[mt]; }
-#else
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const long long row = t.grow0 + pj_row<MT>(mt, lr);
-                pc[mt] = *reinterpret_cast<const f32x4*>(a.cosb + row * 32 + ((pcol & 63) >> 1) + 4 * g);
-                ps[mt] = *reinterpret_cast<const f32x4*>(a.sinb + row * 32 + ((pcol & 63) >> 1) + 4 * g);
-            }
-#endif
         }
     }
 #pragma unroll
@@ -273,12 +264,11 @@ __device__ __forceinline__ void proj_compute(const ProjArgs& a, const TileLoc& t
                 const char* ptr = static_cast<const char*>(a.W) + (p ? (long long)a.Nout * 256 * (long long)sizeof(typename Tag::elem) : 0);
                 bf[i][j][p] = *reinterpret_cast<const u32x4*>(ptr + ((long long)(pj_tile<NTP>(w, 0, j) * NKC + i) * 64 + lane) * 16);
             }
+    // the rotary rows are fetched ONCE (the q pass and the k pass rotate by the same rows) and AHEAD of the MFMA loops, behind the first weight
+    // fragments in the in-order load queue; the standalone kernel requests them before its x tile (both cold, in flight together), the fused tail
+    // has touched them into L2 a GELU step earlier.  Round 3 fetched them at the head of each pass's epilogue: two exposed round trips.
     RopeRows<MT> rr;
-#ifdef LG_PROJ_ROPE_ONCE
-    // experiment: the rotary rows are fetched ONCE (both passes rotate by the same rows) and AHEAD of the MFMA loops — behind the first weight
-    // fragments in the in-order load queue; the standalone kernel requests them before its x tile (both cold, in flight together)
     if constexpr (NTP == 3) { if (preloaded) rr = *preloaded; else proj_rope_load<MT>(a, t, rr); }
-#endif
     __syncthreads();   // the activation tile is complete
     if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8 + stamp_base + 1] = clock64();
     proj_pass<PREC, TA, NTP, NPASS, 0, A_PLANE, MT>(a, t, smA, bf, stamp_base, rr);

@@ -210,18 +210,16 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             for (int nt = 0; nt < 4; ++nt) tail_mma<PREC>(acc[mt][nt], b[nt], af[mt]);
     };
     load_half(0);
-#ifdef LG_TAIL_EARLY_CTX   // experiment: the ctx rows are requested right behind the x rows (they were requested after the first barrier: the
-    // counter being in order, chunk 1's weight fragments — issued behind them — then waited out the whole cold 64 KB ctx load)
-    load_half(1);
-#endif
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i) load_b_A(bf[i], i);
     __builtin_amdgcn_sched_barrier(0);
     store_half(0);
     __syncthreads();
-#ifndef LG_TAIL_EARLY_CTX
-    load_half(1);                       // ctx rows stream in while the x half is multiplied
-#endif
+    // ctx rows stream in while the x half is multiplied.  (What hipcc makes of it, round-4 ISA: it hoists the split arithmetic of store_half(1) up
+    // to here and waits for these loads in front of the loop.  Forcing the conversion back behind the loop — registers laundered through an empty
+    // asm — and / or requesting the ctx rows together with the x rows measured -1.4 % / +-0: the in-order load counter makes chunk 1's weight
+    // fragments wait for the ctx rows either way, and the converted planes are 16 registers instead of 32 through the loop.  LAB_NOTES.md.)
+    load_half(1);
     __builtin_amdgcn_sched_barrier(0);
     constexpr int HC = NKC / 2;         // k-chunks per half
     // The activation fragments of chunk kc + 1 are read from LDS BEFORE the MFMAs of chunk kc (two register sets): with
@@ -245,15 +243,6 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             }
         }
         if (hf == 0) {
-#ifndef LG_TAIL_NO_LAUNDER
-            // the ctx rows' conversion must stay HERE: without the laundering hipcc hoists the pure split arithmetic of store_half(1) to right
-            // behind the loads (16 packed registers instead of 32 through the loop) — and waits for the cold ctx loads BEFORE the first MFMA
-            // (vmcnt(6) .. vmcnt(0) in front of the loop, seen in the ISA in round 4: the whole ctx round trip exposed in every workgroup)
-#pragma unroll
-            for (int i = 0; i < ROUNDS; ++i)
-#pragma unroll
-                for (int j = 0; j < NV; ++j) asm volatile("" : "+v"(hregs[1][i][j]));
-#endif
             store_half(1);
             __syncthreads();
         }
@@ -356,13 +345,11 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             for (int nt = 0; nt < 2; ++nt) tail_mma<PREC>(acc2[mt][nt], b[nt], af[mt]);
     };
     load_b_B(b2f[0], 0); load_b_B(b2f[1], 1); load_b_B(b2f[2], 2);
-#ifdef LG_TAIL_ROPE_PF
-    // experiment: the fused SelfBlock projection opens each pass's epilogue with the rotary rows of this tile (64 rows x 128 B per table, cold:
-    // a full HBM round trip in front of the stores, twice per workgroup).  Touch every line now — behind the first W2 fragments in the in-order
-    // load queue, a whole GELU step before anything younger is waited for — so that the epilogues find them in L2.  No branch around the load.
+    // The fused SelfBlock projection rotates q and k by the rotary rows of this tile (64 rows x 128 B per table, cold).  Touch every line now — behind
+    // the first W2 fragments in the in-order load queue, a whole GELU step before anything younger is waited for — so that the projection's fetch
+    // (lg_proj_body.h proj_rope_load) finds them in L2.  No branch around the load.
     float rope_pf = 0.f;
     if constexpr (NEXT == 1) rope_pf = (((tid >> 6) & 1) ? a.next.sinb : a.next.cosb)[(long long)(t.grow0 + (tid & 63)) * 32 + (tid >> 7) * 8];
-#endif
     gelu_store(0);
     __syncthreads();
     stamp(3);
@@ -399,27 +386,17 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         for (int i = 0; i < CPS; ++i) {
             const int kc = j * CPS + i;
             // j and i are unrolled constants: a plain `if` is resolved at compile time (no join, no conservative wait)
-#ifdef LG_TAIL_PIN_B
-            // experiment: the ring pinned where the source puts it.  Left to itself hipcc issues a chunk's W2 fragments ~1 chunk (step 3: 0 - 7
-            // MFMAs) ahead of their MFMAs instead of 3 (round-4 ISA, tools/isa_wait_distance.py); sched_barrier masks that let the GELU arithmetic
-            // float did not hold the loads (the MFMAs moved instead), so the windows are closed and the GELU of the next n-tile is dealt to them
-            // by hand: row tile i of n-tile j + 1 next to the MFMAs of chunk i
+            // The ring is PINNED where the source puts it (round 4).  Left to itself hipcc issued a chunk's W2 fragments ~1 chunk (last step: 0 - 7
+            // MFMAs) ahead of their MFMAs instead of 3 (tools/isa_wait_distance.py); sched_barrier masks that let the GELU arithmetic float did
+            // not hold the loads (the MFMAs moved instead), so the windows are closed and the GELU of the next n-tile is dealt to them by hand:
+            // row tile i of n-tile j + 1 next to the MFMAs of chunk i.  cfg #2 +0.7 %, cfg #5' +2 % (profiles/r04e_*, r04f_*).
             __builtin_amdgcn_sched_barrier(0);
             if (kc + 3 < NKC) load_b_B(b2f[(kc + 3) & 3], kc + 3);
             __builtin_amdgcn_sched_barrier(0);
             chunk_B(kc, b2f[kc & 3]);
             if (j < 3) gelu_store(j + 1, i * MT / CPS, (i + 1) * MT / CPS);
-#else
-            if (kc + 3 < NKC) load_b_B(b2f[(kc + 3) & 3], kc + 3);
-            chunk_B(kc, b2f[kc & 3]);
-#endif
         }
-        if (j < 3) {
-#ifndef LG_TAIL_PIN_B
-            gelu_store(j + 1);
-#endif
-            __syncthreads();
-        }
+        if (j < 3) __syncthreads();
     }
     stamp(4);
     // ------------------------------------------------------------------ epilogue: + b2, + x, store; next block's activation tile
@@ -482,9 +459,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         }
     }
     stamp(5);
-#ifdef LG_TAIL_ROPE_PF
     asm volatile("" :: "v"(rope_pf));   // keeps the touch alive (and waits for it here at the latest)
-#endif
     if constexpr (NEXT == 3) final_compute<PREC, G_PLANE, MT>(a.fin, t, smem);
     else if constexpr (NEXT != 0) proj_compute<(prec_is_split(PREC) ? (ASPLIT ? PREC_F16X3 : PREC_QKV_F16W2) : PREC), TA, NEXT == 1 ? 3 : 2, 2, G_PLANE, MT>(a.next, t, smem, 0);
     if (a.dbg && lane == 0)   // wall clock at the end + where the workgroup ran (HW_ID, XCC_ID)

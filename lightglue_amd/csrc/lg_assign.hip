@@ -33,10 +33,6 @@ __device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2
 // Column statistics are per-thread registers across the rows, written as per-row-tile partials [tile][column] and
 // merged by the next kernel.
 constexpr int ART = 32;
-#ifndef LG_SWEEP_PF
-#define LG_SWEEP_PF 4
-#endif
-constexpr int PF = LG_SWEEP_PF;   // rows of the similarity matrix each thread keeps in flight in the two sweeps
 
 // (m, s) <- log-sum-exp merge with (m2, s2), ONE exponential: e = exp(-|m - m2|) scales the smaller side
 __device__ __forceinline__ void lse_merge1(float& m, float& s, float m2, float s2) {
@@ -63,19 +59,11 @@ __global__ __launch_bounds__(256) void lse_sweep_kernel(AssignArgs a) {
         const bool act = c < len1;                         // this thread's 4 columns hold at least one live column
         const float* col = simp + (act ? c : 0);
         float cm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, cs[4] = {0.f, 0.f, 0.f, 0.f};
-        // PF rows in flight per thread (clamped, never branched).  One row ahead left 4 KB per workgroup = 16 KB per CU in flight at cfg #2
-        // (four workgroups per CU) against the ~64 KB per CU that 8 TB/s x ~2 us of latency need: the sweeps sat at 4.1 TB/s
-        f32x4 ring[PF];
-#pragma unroll
-        for (int i = 0; i < PF; ++i) ring[i] = *reinterpret_cast<const f32x4*>(col + (long long)min(i, rows - 1) * a.rs.cap1);
+        f32x4 nxt = *reinterpret_cast<const f32x4*>(col);
 #pragma unroll 1
-        for (int r0 = 0; r0 < rows; r0 += PF) {
-#pragma unroll
-          for (int ri = 0; ri < PF; ++ri) {
-            const int r = r0 + ri;
-            if (r >= rows) break;                       // workgroup-uniform
-            f32x4 v = ring[ri];
-            ring[ri] = *reinterpret_cast<const f32x4*>(col + (long long)min(r + PF, rows - 1) * a.rs.cap1);
+        for (int r = 0; r < rows; ++r) {
+            f32x4 v = nxt;
+            nxt = *reinterpret_cast<const f32x4*>(col + (long long)min(r + 1, rows - 1) * a.rs.cap1);   // next row in flight
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (!act || c + i >= len1) v[i] = -INFINITY;
             // row statistic: the WAVE's maximum first (12 DPP / permlane ops), then every lane exponentiates against it and the
@@ -92,7 +80,6 @@ __global__ __launch_bounds__(256) void lse_sweep_kernel(AssignArgs a) {
                 if (c0 == 0) { shm[wave][r] = m; shs[wave][r] = sum; }
                 else { float mo = shm[wave][r], so = shs[wave][r]; lse_merge1(mo, so, m, sum); shm[wave][r] = mo; shs[wave][r] = so; }
             }
-          }
         }
         if (act) {
             *reinterpret_cast<f32x4*>(pm + c) = f32x4{cm[0], cm[1], cm[2], cm[3]};
@@ -159,17 +146,11 @@ __global__ __launch_bounds__(256) void argmax_sweep_kernel(AssignArgs a) {
         const f32x4 lc = *reinterpret_cast<const f32x4*>(lsec + cc);
         const f32x4 l1 = *reinterpret_cast<const f32x4*>(ls1 + cc);
         float cb[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}; int ci[4] = {0, 0, 0, 0};
-        f32x4 ring[PF];                                  // PF rows in flight per thread, as in sweep 1
-#pragma unroll
-        for (int i = 0; i < PF; ++i) ring[i] = *reinterpret_cast<const f32x4*>(col + (long long)min(i, rows - 1) * a.rs.cap1);
+        f32x4 nxt = *reinterpret_cast<const f32x4*>(col);
 #pragma unroll 1
-        for (int r0 = 0; r0 < rows; r0 += PF) {
-#pragma unroll
-          for (int ri = 0; ri < PF; ++ri) {
-            const int r = r0 + ri;
-            if (r >= rows) break;                       // workgroup-uniform
-            const f32x4 v = ring[ri];
-            ring[ri] = *reinterpret_cast<const f32x4*>(col + (long long)min(r + PF, rows - 1) * a.rs.cap1);
+        for (int r = 0; r < rows; ++r) {
+            const f32x4 v = nxt;
+            nxt = *reinterpret_cast<const f32x4*>(col + (long long)min(r + 1, rows - 1) * a.rs.cap1);
             const float lr = lser[r], l0 = ls0[r];
             float best = -INFINITY; int bi = 0x7fffffff;
 #pragma unroll
@@ -188,7 +169,6 @@ __global__ __launch_bounds__(256) void argmax_sweep_kernel(AssignArgs a) {
             if (lane == 0) {
                 if (c0 == 0 || wbest > shb[wave][r]) { shb[wave][r] = wbest; shi[wave][r] = wbi; }   // later passes = higher columns: strict >
             }
-          }
         }
         if (act) {
             *reinterpret_cast<f32x4*>(pv + c) = f32x4{cb[0], cb[1], cb[2], cb[3]};

@@ -97,7 +97,10 @@ __device__ __forceinline__ void proj_rope_load(const ProjArgs& a, const TileLoc&
         rr.s[mt] = *reinterpret_cast<const f32x4*>(a.sinb + row * 32 + ((pcol & 63) >> 1) + 4 * g);
     }
 }
-template <int PREC, class TA, int NTP, int NPASS, int PASS, int A_PLANE, int MT>
+// AHEAD (the fused tail's form): activation fragments read from LDS one chunk ahead of their MFMAs and the biases requested ahead of the loop.  The
+// standalone kernel keeps the round-3 order (fragments and biases right where they are used): with AHEAD it measured 0.114 -> 0.118 ms per launch
+// (profiles/r04g_ab_cfg2.log), the fused tail -1.5 %.
+template <int PREC, class TA, int NTP, int NPASS, int PASS, int A_PLANE, int MT, bool AHEAD>
 __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, const char* smA, u32x4 (&bf)[PJ<PREC>::NPART == 2 ? 2 : 4][NTP][PJ<PREC>::NPART],
                                           int stamp_base, const RopeRows<MT>& rr) {
     typedef typename PJ<PREC>::Tag Tag;
@@ -119,11 +122,41 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
 #pragma unroll
             for (int p = 0; p < NPART; ++p) dst[j][p] = wfrag(p, pj_tile<NTP>(w, pass, j), kc);
     };
+    constexpr bool HAS_PAIR = !pj_is_v<NTP>(PASS, 0);          // slots 0, 1 = a q / k pair
+    constexpr bool ROPE = NTP == 3;                            // SelfBlock: rotary on q and k (ref :58-65)
+    const int pcol = (NTP == 3 ? PASS * 256 : 0) + 32 * w;     // first packed column of the pair: [group][head][64]
+    f32x4 pb[2]; f32x4 pc[MT], ps[MT]; float bv[NTP];
+    auto load_operands = [&]() {                               // the epilogue's operands: biases (shared by every workgroup: L2 / L1 hits); rotary rows from `rr`
+        if constexpr (HAS_PAIR) {
+            pb[0] = *reinterpret_cast<const f32x4*>(a.bias + pcol + 8 * g); pb[1] = *reinterpret_cast<const f32x4*>(a.bias + pcol + 8 * g + 4);
+            if constexpr (ROPE) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) { pc[mt] = rr.c[mt]; ps[mt] = rr.s[mt]; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NTP; ++j)
+            if (pj_is_v<NTP>(PASS, j)) bv[j] = a.bias[pj_tile<NTP>(w, PASS, j) * 16 + lr];
+    };
+    if constexpr (AHEAD) load_operands();
     f32x4 acc[MT][NTP];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NTP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // AHEAD: activation fragments are read from LDS one chunk ahead of their MFMAs (two register sets; round-4 ISA: read right in front of the
+    // MFMAs they cost every chunk an exposed LDS round trip); a pass's first chunk reads its own
+    static_assert(MT <= 4 && NBUF % 2 == 0, "row tiles per workgroup / ring depth");
+    u32x4 afh[2][MT][APART];
+    auto read_af = [&](u32x4 (&af)[MT][APART], int kc) {
+        const char* tile = smA + (kc >> 1) * TILE;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int p = 0; p < APART; ++p)
+                af[mt][p] = *reinterpret_cast<const u32x4*>(tile + p * A_PLANE + pj_tile_off(pj_row<MT>(mt, lr), (kc & 1) * 4 + g));
+    };
+    if constexpr (AHEAD) read_af(afh[0], 0);
 #pragma unroll 1
     for (int c0 = 0; c0 < NKC; c0 += NBUF) {
 #pragma unroll
@@ -133,49 +166,26 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
             const int nk = kc + NBUF - 1;
             const int npass = nk < NKC ? PASS : (PASS + 1 < NPASS ? PASS + 1 : PASS);
             load_b(bf[(i + NBUF - 1) % NBUF], npass, nk < NKC ? nk : nk - NKC);
+            if constexpr (AHEAD) read_af(afh[(i + 1) & 1], kc + 1 < NKC ? kc + 1 : kc);
             __builtin_amdgcn_sched_barrier(0);
-            const char* tile = smA + (kc >> 1) * TILE;
+            if constexpr (!AHEAD) read_af(afh[i & 1], kc);
 #pragma unroll
-            for (int mh = 0; mh < MT; mh += 4) {   // activation fragments of (up to) 4 row tiles at a time (bounds the live registers at MT = 8)
-            constexpr int MG = MT < 4 ? MT : 4;
-            u32x4 afh[MG][APART];
-#pragma unroll
-            for (int mt = 0; mt < MG; ++mt)
-#pragma unroll
-                for (int p = 0; p < APART; ++p)
-                    afh[mt][p] = *reinterpret_cast<const u32x4*>(tile + p * A_PLANE + pj_tile_off(pj_row<MT>(mh + mt, lr), (kc & 1) * 4 + g));
-#pragma unroll
-            for (int mtl = 0; mtl < MG; ++mtl)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int j = 0; j < NTP; ++j) {
-                    if (pj_is_v<NTP>(PASS, j)) pj_mma<PREC, false>(acc[mh + mtl][j], bf[i][j], afh[mtl]);   // compile-time after unrolling
-                    else pj_mma<PREC, true>(acc[mh + mtl][j], bf[i][j], afh[mtl]);
+                    if (pj_is_v<NTP>(PASS, j)) pj_mma<PREC, false>(acc[mt][j], bf[i][j], afh[i & 1][mt]);   // compile-time after unrolling
+                    else pj_mma<PREC, true>(acc[mt][j], bf[i][j], afh[i & 1][mt]);
                 }
-            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     stamp(2 + 2 * PASS);
-    // ---- epilogue of the pass, straight from the accumulators.  All loads (bias, rotary tables) are issued BEFORE the first
-    // store: the compiler cannot prove that q/k/v do not alias the tables, so a load placed after a store stays there and
-    // every (tile, 16-row tile) iteration would expose one full L2 round trip (measured: 14k cycles for 12 iterations).
+    // ---- epilogue of the pass, straight from the accumulators.  All loads come BEFORE the first store: the compiler cannot prove that q / k / v do
+    // not alias the tables, so a load placed after a store stays there (one exposed round trip per iteration)
+    if constexpr (!AHEAD) load_operands();
     typedef TA ta4 __attribute__((ext_vector_type(4)));
     constexpr int OPART = PJ<PREC>::OPART;
     static_assert(OPART == 1 || sizeof(TA) == 2, "split q / k / v planes are f16");
-    constexpr bool HAS_PAIR = !pj_is_v<NTP>(PASS, 0);          // slots 0, 1 = a q / k pair
-    constexpr bool ROPE = NTP == 3;                            // SelfBlock: rotary on q and k (ref :58-65)
-    const int pcol = (NTP == 3 ? PASS * 256 : 0) + 32 * w;     // first packed column of the pair: [group][head][64]
-    f32x4 pb[2]; f32x4 pc[MT], ps[MT]; float bv[NTP];
-    if constexpr (HAS_PAIR) {
-        pb[0] = *reinterpret_cast<const f32x4*>(a.bias + pcol + 8 * g); pb[1] = *reinterpret_cast<const f32x4*>(a.bias + pcol + 8 * g + 4);
-        if constexpr (ROPE) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) { pc[mt] = rr.c[mt]; ps[mt] = rr.s[mt]; }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < NTP; ++j)
-        if (pj_is_v<NTP>(PASS, j)) bv[j] = a.bias[pj_tile<NTP>(w, PASS, j) * 16 + lr];
     if constexpr (HAS_PAIR) {                                  // q / k (or qk) pair: 8 consecutive channels per lane and keypoint row
         TA* base = static_cast<TA*>((NTP == 3 && PASS == 1) ? a.k : a.q);
         const int head = (pcol >> 6) & 3, d0 = pcol & 63;
@@ -246,7 +256,7 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
 
 // NTP = n-tiles per wave per pass: self (768 columns) 3 x 2 passes, cross (512 columns) 2 x 2.  A_PLANE = byte distance
 // between the hi and lo planes of the activation tile in LDS; MT = 16-row tiles of the workgroup's row tile (4 or 8).
-template <int PREC, class TA, int NTP, int NPASS, int A_PLANE = PJL<PREC>::A_PLANE, int MT = 4>
+template <int PREC, class TA, int NTP, int NPASS, int A_PLANE = PJL<PREC>::A_PLANE, int MT = 4, bool AHEAD = false>
 __device__ __forceinline__ void proj_compute(const ProjArgs& a, const TileLoc& t, const char* smA, int stamp_base, const RopeRows<MT>* preloaded = nullptr) {
     static_assert(NPASS == 2, "two passes");
     typedef typename PJ<PREC>::Tag Tag;
@@ -271,8 +281,8 @@ __device__ __forceinline__ void proj_compute(const ProjArgs& a, const TileLoc& t
     if constexpr (NTP == 3) { if (preloaded) rr = *preloaded; else proj_rope_load<MT>(a, t, rr); }
     __syncthreads();   // the activation tile is complete
     if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8 + stamp_base + 1] = clock64();
-    proj_pass<PREC, TA, NTP, NPASS, 0, A_PLANE, MT>(a, t, smA, bf, stamp_base, rr);
-    proj_pass<PREC, TA, NTP, NPASS, 1, A_PLANE, MT>(a, t, smA, bf, stamp_base, rr);
+    proj_pass<PREC, TA, NTP, NPASS, 0, A_PLANE, MT, AHEAD>(a, t, smA, bf, stamp_base, rr);
+    proj_pass<PREC, TA, NTP, NPASS, 1, A_PLANE, MT, AHEAD>(a, t, smA, bf, stamp_base, rr);
 }
 
 // The final projection of the log assignment (ref :289-291) on a 64 x 256 activation tile in LDS (same layout and precondition as

@@ -331,14 +331,19 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
 #pragma unroll
             for (int p = 0; p < NPART; ++p) dst[nt][p] = wfrag(W2, p, 256LL * 512, w * 2 + nt, kc);
     };
-    auto chunk_B = [&](int kc, const u32x4 (&b)[2][NPART]) {
+    // activation (g) fragments of one k-chunk, read one chunk AHEAD of their MFMAs inside a step (two register sets, as in phase A; round-4 ISA: read
+    // right in front of the MFMAs they cost every chunk an exposed LDS round trip).  A step's first chunk reads its own: the tile it needs is
+    // published by the barrier in front of it.
+    u32x4 afB[2][MT][NPART];
+    auto read_afB = [&](u32x4 (&af)[MT][NPART], int kc) {
         const char* tile = smem + (kc >> 1) * TILE;
-        u32x4 af[MT][NPART];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int p = 0; p < NPART; ++p)
                 af[mt][p] = *reinterpret_cast<const u32x4*>(tile + p * G_PLANE + lds_off<128>(mt * 16 + lr, (kc & 1) * 4 + g));
+    };
+    auto mma_B = [&](const u32x4 (&af)[MT][NPART], const u32x4 (&b)[2][NPART]) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -390,10 +395,12 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             // MFMAs) ahead of their MFMAs instead of 3 (tools/isa_wait_distance.py); sched_barrier masks that let the GELU arithmetic float did
             // not hold the loads (the MFMAs moved instead), so the windows are closed and the GELU of the next n-tile is dealt to them by hand:
             // row tile i of n-tile j + 1 next to the MFMAs of chunk i.  cfg #2 +0.7 %, cfg #5' +2 % (profiles/r04e_*, r04f_*).
+            if (i == 0) read_afB(afB[0], kc);
             __builtin_amdgcn_sched_barrier(0);
             if (kc + 3 < NKC) load_b_B(b2f[(kc + 3) & 3], kc + 3);
+            if (i + 1 < CPS) read_afB(afB[(i + 1) & 1], kc + 1);
             __builtin_amdgcn_sched_barrier(0);
-            chunk_B(kc, b2f[kc & 3]);
+            mma_B(afB[i & 1], b2f[kc & 3]);
             if (j < 3) gelu_store(j + 1, i * MT / CPS, (i + 1) * MT / CPS);
         }
         if (j < 3) __syncthreads();
@@ -461,7 +468,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     stamp(5);
     asm volatile("" :: "v"(rope_pf));   // keeps the touch alive (and waits for it here at the latest)
     if constexpr (NEXT == 3) final_compute<PREC, G_PLANE, MT>(a.fin, t, smem);
-    else if constexpr (NEXT != 0) proj_compute<(prec_is_split(PREC) ? (ASPLIT ? PREC_F16X3 : PREC_QKV_F16W2) : PREC), TA, NEXT == 1 ? 3 : 2, 2, G_PLANE, MT>(a.next, t, smem, 0);
+    else if constexpr (NEXT != 0) proj_compute<(prec_is_split(PREC) ? (ASPLIT ? PREC_F16X3 : PREC_QKV_F16W2) : PREC), TA, NEXT == 1 ? 3 : 2, 2, G_PLANE, MT, true>(a.next, t, smem, 0);
     if (a.dbg && lane == 0)   // wall clock at the end + where the workgroup ran (HW_ID, XCC_ID)
         a.dbg[((long long)blockIdx.x * 8 + w) * 8 + 7] = (wall_clock64() & ((1LL << 44) - 1)) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFF00) << 40) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 44);
 }

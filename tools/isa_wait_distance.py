@@ -49,6 +49,20 @@ def main():
                     print(f"+{i:5d} {t:32s} waits for {y[2]} issued {d_i:4d} instr / {d_m:3d} MFMAs earlier (+{y[0]}); {len(must)} op(s) retire; since barrier {i - last_bar}; next: {nxt[:60]}")
                 q = q[len(q) - n:]
     print(f"{len(body)} instructions, {mf} MFMAs")
+    if "--lds" in sys.argv:   # the same for LDS reads (lgkmcnt; scalar loads share the counter and return out of order: prologue lines are approximate)
+        q, mf = [], 0
+        for i, t in enumerate(body):
+            if t.startswith("v_mfma"):
+                mf += 1
+            elif t.startswith("ds_") or t.startswith("s_load") or t.startswith("s_buffer_load"):
+                q.append((i, mf, t.split()[0]))
+            elif t.startswith("s_waitcnt") and "lgkmcnt" in t:
+                n = int(re.search(r"lgkmcnt\((\d+)\)", t).group(1))
+                if len(q) > n:
+                    y = q[len(q) - n - 1]
+                    if mf - y[1] <= lim and y[2].startswith("ds_read"):
+                        print(f"+{i:5d} {t:32s} waits for {y[2]} issued {i - y[0]:4d} instr / {mf - y[1]:3d} MFMAs earlier")
+                    q = q[len(q) - n:]
 
 
 if __name__ == "__main__":

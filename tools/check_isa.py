@@ -86,6 +86,8 @@ def check_kernel(name, body):
     # loop headers: the first barrier after a header must be preceded by a vmcnt(0) wait, no DMA in between
     for i, t in enumerate(body):
         if re.match(r"^\.LBB\w+:.*Loop Header", t):
+            if not any(is_dma(x) for x in body[i + 1:]):
+                continue                               # no DMA is issued from here on: nothing can be published through this loop's back edge
             seen_wait = False
             for k in range(i + 1, n):
                 if is_dma(body[k]):

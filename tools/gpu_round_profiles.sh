@@ -3,7 +3,7 @@
 #   GPU tests + smoke, bench (default, fast opt-in, recipe D), 2-rank flow test, kernel traces (cfg #2, cfg #4 shard, adaptive cfg #3', B = 1),
 #   PMC passes (SQ / FETCH_SIZE / WRITE_SIZE in their own runs, kernel trace only) for cfg #2 and for the adaptive case, all BASELINE
 #   configs on one GPU, B = 1 latency, SuperPoint extractor
-O=gpurun_out/round; mkdir -p $O
+O=gpurun_out/round; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -q > $O/gputests.log 2>&1; grep -E 'passed|failed|error' $O/gputests.log | tail -4   # (the full log is kept: a failure must be readable afterwards)
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2

@@ -140,6 +140,17 @@ __device__ __forceinline__ void lds_dma16(const void* gptr, void* lds) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(gptr) : "memory", "m0");
 }
 
+// ---- weight fragments by buffer load: the fragment-packed weight arrays are read as base descriptor (SGPRs) + one per-lane VGPR offset (16 lane,
+// constant for the kernel) + a SCALAR byte offset per fragment.  As plain global loads hipcc built a 64-bit VGPR address per load (v_lshl_add_u64 +
+// v_add_co / v_addc pairs and an s_nop in front of each load: 12 VALU + 7 s_nop per k-chunk of the tail's phase A, round-4 ISA), all of it in the gap
+// between two MFMA runs; the scalar adds co-issue.  Same cache path, same in-order counter.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFF0, 0x00020000);
+}
+__device__ __forceinline__ u32x4 weight_frag(__amdgpu_buffer_rsrc_t rs, int lane_off, int byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, byte_off, 0);
+}
+
 // ---- row space
 struct RowSpace {
     int B;            // pairs in this forward

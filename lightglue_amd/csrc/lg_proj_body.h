@@ -112,9 +112,10 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
     auto stamp = [&](int slot) {   // profiling tap (a.dbg == nullptr in production)
         if (a.dbg && lane == 0) a.dbg[((long long)blockIdx.x * 8 + w) * 8 + stamp_base + slot] = clock64();
     };
+    const __amdgpu_buffer_rsrc_t wrs = weight_rsrc(a.W);
+    const int lane16 = lane * 16;
     auto wfrag = [&](int p, int nt, int kc) -> u32x4 {
-        const char* ptr = static_cast<const char*>(a.W) + (p ? (long long)a.Nout * 256 * (long long)sizeof(typename Tag::elem) : 0);
-        return *reinterpret_cast<const u32x4*>(ptr + ((long long)(nt * NKC + kc) * 64 + lane) * 16);
+        return weight_frag(wrs, lane16, (p ? a.Nout * 256 * (int)sizeof(typename Tag::elem) : 0) + (nt * NKC + kc) * 1024);
     };
     auto load_b = [&](u32x4 (&dst)[NTP][NPART], int pass, int kc) {
 #pragma unroll
@@ -271,8 +272,7 @@ __device__ __forceinline__ void proj_compute(const ProjArgs& a, const TileLoc& t
         for (int j = 0; j < NTP; ++j)
 #pragma unroll
             for (int p = 0; p < NPART; ++p) {
-                const char* ptr = static_cast<const char*>(a.W) + (p ? (long long)a.Nout * 256 * (long long)sizeof(typename Tag::elem) : 0);
-                bf[i][j][p] = *reinterpret_cast<const u32x4*>(ptr + ((long long)(pj_tile<NTP>(w, 0, j) * NKC + i) * 64 + lane) * 16);
+                bf[i][j][p] = weight_frag(weight_rsrc(a.W), lane * 16, (p ? a.Nout * 256 * (int)sizeof(typename Tag::elem) : 0) + (pj_tile<NTP>(w, 0, j) * NKC + i) * 1024);
             }
     // the rotary rows are fetched ONCE (the q pass and the k pass rotate by the same rows) and AHEAD of the MFMA loops, behind the first weight
     // fragments in the in-order load queue; the standalone kernel requests them before its x tile (both cold, in flight together), the fused tail
@@ -298,11 +298,11 @@ __device__ __forceinline__ void final_compute(const FinalArgs& a, const TileLoc&
     constexpr int NBUF = 4;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, g = lane >> 4;
     const int layer = a.layer_of_pair ? a.layer_of_pair[t.pair] : 0;
-    const char* W = static_cast<const char*>(a.W) + (long long)layer * a.w_layer_bytes;
+    const __amdgpu_buffer_rsrc_t wrs = weight_rsrc(static_cast<const char*>(a.W) + (long long)layer * a.w_layer_bytes);
     const float* bias = a.bias + (long long)layer * 256;
+    const int lane16 = lane * 16;
     auto wfrag = [&](int p, int nt, int kc) -> u32x4 {
-        const char* ptr = W + (p ? 256LL * 256 * (long long)sizeof(typename Tag::elem) : 0);
-        return *reinterpret_cast<const u32x4*>(ptr + ((long long)(nt * NKC + kc) * 64 + lane) * 16);
+        return weight_frag(wrs, lane16, (p ? 256 * 256 * (int)sizeof(typename Tag::elem) : 0) + (nt * NKC + kc) * 1024);
     };
     auto load_b = [&](u32x4 (&dst)[2][NPART], int kc) {
 #pragma unroll

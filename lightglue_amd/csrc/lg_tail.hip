@@ -144,12 +144,12 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     }
 
     // weight fragment: plane p, n-tile nt, k-chunk kc -> 64 lanes x 16 B contiguous
-    auto wfrag = [&](const void* base, int p, long long plane_elems, int nt, int kc) -> u32x4 {
-        const char* ptr = static_cast<const char*>(base) + (p ? plane_elems * (long long)sizeof(typename Tag::elem) : 0);
-        return *reinterpret_cast<const u32x4*>(ptr + ((long long)(nt * NKC + kc) * 64 + lane) * 16);
+    // by BUFFER load (lg_common.h weight_rsrc): descriptor + constant per-lane offset + scalar byte offset — no VALU address arithmetic between MFMA runs
+    const __amdgpu_buffer_rsrc_t Wc = weight_rsrc(a.Wcat), W2 = weight_rsrc(a.W2);
+    const int lane16 = lane * 16;
+    auto wfrag = [&](__amdgpu_buffer_rsrc_t base, int p, long long plane_elems, int nt, int kc) -> u32x4 {
+        return weight_frag(base, lane16, (p ? (int)(plane_elems * (long long)sizeof(typename Tag::elem)) : 0) + (nt * NKC + kc) * 1024);
     };
-    const void* Wc = a.Wcat;
-    const void* W2 = a.W2;
 
     // ---- activation tile -> LDS.  Half hf (0: x, 1: ctx) = TBM rows x 256 floats = STAGES/2 K-stage tiles.
     // A stage tile is TBM rows x 8 chunks of 16 bytes = 128 MT threads' worth, so the 512 threads cover 4 / MT stage tiles

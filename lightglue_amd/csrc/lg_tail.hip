@@ -394,14 +394,17 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             // The ring is PINNED where the source puts it (round 4).  Left to itself hipcc issued a chunk's W2 fragments ~1 chunk (last step: 0 - 7
             // MFMAs) ahead of their MFMAs instead of 3 (tools/isa_wait_distance.py); sched_barrier masks that let the GELU arithmetic float did
             // not hold the loads (the MFMAs moved instead), so the windows are closed and the GELU of the next n-tile is dealt to them by hand:
-            // row tile i of n-tile j + 1 next to the MFMAs of chunk i.  cfg #2 +0.7 %, cfg #5' +2 % (profiles/r04e_*, r04f_*).
+            // row tile i of n-tile j + 1 with chunk i.  cfg #2 +0.7 %, cfg #5' +2 % (profiles/r04e_*, r04f_*).
             if (i == 0) read_afB(afB[0], kc);
             __builtin_amdgcn_sched_barrier(0);
             if (kc + 3 < NKC) load_b_B(b2f[(kc + 3) & 3], kc + 3);
             if (i + 1 < CPS) read_afB(afB[(i + 1) & 1], kc + 1);
             __builtin_amdgcn_sched_barrier(0);
-            mma_B(afB[i & 1], b2f[kc & 3]);
+            // the chunk's GELU piece as ONE block in FRONT of its MFMA run (round 4, call p: left in the same window hipcc sprinkles 3 - 5 VALU between every
+            // two MFMAs; as a block behind the run +-0, in front of it tail -1.1 %: a wave's VALU block then meets its partner's MFMA run)
             if (j < 3) gelu_store(j + 1, i * MT / CPS, (i + 1) * MT / CPS);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_B(afB[i & 1], b2f[kc & 3]);
         }
         if (j < 3) __syncthreads();
     }

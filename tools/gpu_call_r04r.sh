@@ -1,0 +1,12 @@
+#!/bin/bash
+# Round-4 call r: split attention — the next tile's DMA issue behind the first (dl1) / the last (dl4) S^T MFMA group instead of at the head of the segment after the barrier
+O=gpurun_out/r04r; mkdir -p $O
+export TMPDIR=/tmp
+NEW=lightglue_amd/liblightglue_amd.so
+for round in 1 2 3 4; do for lib in $NEW build_variants/liblightglue_amd_dl1.so build_variants/liblightglue_amd_dl4.so; do
+  LIGHTGLUE_AMD_LIB=$PWD/$lib timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['kernel_ms_per_step']; print('$lib', round(d['value']), round(d['ms_per_step'],3), {x: round(k[x],3) for x in ('attn_self','attn_cross','fused_tail') if x in k}, d['parity']['index_mismatches'], d['parity']['max_dscore'])"
+done; done 2>&1 | tee $O/ab_cfg2.log
+for lib in $NEW build_variants/liblightglue_amd_dl1.so; do
+  echo "== $lib" | tee -a $O/ab_configs.log
+  LIGHTGLUE_AMD_LIB=$PWD/$lib timeout 600 python tools/bench_configs.py "#3' " "#4 " 2>&1 | grep "^|" | tee -a $O/ab_configs.log
+done

@@ -139,7 +139,7 @@ int lg_debug_mfma_sustained(double* tflops, double* mhz, void* hip_stream);
  * 10 LayerNorm+GELU, 11 ffn.3+residual. */
 int lg_engine_debug_stop_after(lg_engine* e, int32_t step);
 /* Copy an internal buffer to host (synchronises the device).  Names: X CTX MSG H1 G Q K VT COS SIN MD
- * SIM LS CONF MSCORE LSE_R LSE_C IND LEN FINAL_LAYER.  *nbytes_out receives the buffer's byte size;
+ * SIM LS LSNEG CONF MSCORE LSE_R LSE_C IND LEN FINAL_LAYER.  *nbytes_out receives the buffer's byte size;
  * at most max_bytes are copied. */
 int lg_engine_debug_read(lg_engine* e, const char* name, void* host_dst, int64_t max_bytes, int64_t* nbytes_out);
 /* Row capacities chosen for the last forward (multiples of 128) -> global row = pair*(cap0+cap1) + image*cap0 + r */

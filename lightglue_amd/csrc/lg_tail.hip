@@ -27,13 +27,20 @@
 //            multiplied -> two barriers for the whole phase, weight fragments prefetched from L2 on a ring.
 //   LN       per-wave (mean, M2) over its 64 hidden units in registers, ONE exchange through LDS, merged with the
 //            parallel-variance formula (exactly a two-pass variance; one barrier pair instead of two)
-//   phase B  out = g W2^T + b2 in 4 steps: step j multiplies K-stages 2j, 2j+1 of g (128 hidden units), then the
-//            wave applies GELU to its next n-tile and writes it to LDS as 8-byte pieces (one barrier per step).
-//   epilogue residual add and x store straight from the accumulators (16 bytes per lane, 64 contiguous bytes per row)
+//   phase B  out = g W2^T + b2 in 4 steps: step j multiplies K-stages 2j, 2j+1 of g (128 hidden units) in 4 k-chunks; the GELU of
+//            the wave's NEXT n-tile is dealt to those chunks by row tile, each piece as one VALU block in FRONT of its chunk's MFMA
+//            run, written to LDS as 8-byte pieces (one barrier per step).  Closed sched_barrier windows pin the W2 ring 3 chunks and
+//            the LDS fragment reads 1 chunk ahead (round 4: hipcc sinks both next to their use otherwise).
+//   weights  every fragment stream is a raw buffer load: descriptor + constant per-lane offset + SCALAR byte offset (lg_common.h
+//            weight_rsrc) — no VALU address arithmetic in the gaps between MFMA runs, which is where this kernel's time goes
+//            (two waves share a fully paced matrix pipe: phase A reaches ~77 % of it with no memory instruction in the loop at all).
+//   epilogue residual add and x store straight from the accumulators (16 bytes per lane, 64 contiguous bytes per row); optional
+//            256 -> 1 heads on the new rows (token confidence, matchability as sigmoid and as the assignment's log-sigmoid terms)
 //   next     (optional, NEXT != 0) the new x tile is ALSO written to LDS in operand precision — into K-stages 0..3 of
 //            the g planes, which are dead once every wave has entered step 3, so no barrier is needed in front of it —
 //            and the NEXT block's q/k/v projection (lg_proj_body.h; SelfBlock -> this layer's CrossBlock, CrossBlock ->
 //            next layer's SelfBlock) runs here: saves that kernel's launch, its x-tile read + conversion and a grid drain.
+//            NEXT == 3: the LAST tail of a fixed-depth forward runs the final projection of the log assignment instead.
 #include "lg_proj_body.h"
 
 namespace lg {

@@ -116,6 +116,8 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream);
  *   "fused_tail"   1  out_proj + ffn + LayerNorm + GELU + residual as one kernel (lg_tail.hip); 0 = per-op GEMM kernels
  *   "fused_next"   1  the tail kernel also runs the NEXT block's q/k/v projection on the x tile it has just produced
  *                     (bit-identical to the separate kernel; needs fused_tail and 16-bit operand precisions)
+ *   "fused_prep"   1  input_dim == 256: keypoint normalisation, Fourier rotary rows, index set and the descriptor copy run inside the first
+ *                     projection launch instead of their own kernel (bit-identical; debug stops use the separate kernel)
  *   "attn_rows"    -  query rows per attention wave: 16 | 32 | 64 (bit-identical outputs; the split attention has 16 | 32).  Unset:
  *                     32, and 16 when a launch has fewer 128-row workgroups than the chip has CUs (single pairs); setting it pins
  *                     the shape

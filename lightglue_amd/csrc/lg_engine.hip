@@ -107,7 +107,7 @@ struct lg_engine {
     size_t sqkv_layer_bytes = 0, cqkv_layer_bytes = 0, final_layer_bytes = 0;
     bool attn_dma = true;   // option "attn_dma": LDS-DMA attention kernel (16-bit operands, 32 rows per wave)
     int attn_rows = 32;   // query rows per attention wave (32 | 64), option "attn_rows" / env LG_ATTN_ROWS
-    int fused_tail = 1, fused_next = 1;
+    int fused_tail = 1, fused_next = 1, fused_prep = 1;   // fused_prep: the per-keypoint preparation inside the first projection launch (input_dim == 256)
     int tail_timing = 0; long long* TAILDBG = nullptr; long long* TAILDBG2 = nullptr;
     int* CFLAGS = nullptr; int compact_epoch = 0; bool cflags_clean = false;   // compaction chunk flags [2B][cap / 128] + 1 error word (lg_adaptive.hip)
     int tail_row_tiles = 0;   // option "tail_row_tiles": 16-row tiles per fused-tail workgroup; 0 = by grid fill (4 | 2 | 1)
@@ -539,6 +539,7 @@ int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
     if (!e || !key) return fail(LG_ERR_INVALID, "null argument");
     if (std::strcmp(key, "fused_tail") == 0) { e->fused_tail = value != 0; return LG_OK; }
     if (std::strcmp(key, "fused_next") == 0) { e->fused_next = value != 0; return LG_OK; }
+    if (std::strcmp(key, "fused_prep") == 0) { e->fused_prep = value != 0; return LG_OK; }
     if (std::strcmp(key, "attn_dma") == 0) { e->attn_dma = value != 0; return LG_OK; }
     if (std::strcmp(key, "attn_rows") == 0) { if (value != 16 && value != 32 && value != 64) return fail(LG_ERR_INVALID, "attn_rows must be 16, 32 or 64"); e->attn_rows = value; e->attn_auto_rows = false; return LG_OK; }
     if (std::strcmp(key, "tail_row_tiles") == 0) { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(LG_ERR_INVALID, "tail_row_tiles must be 0 (automatic), 1, 2 or 4"); e->tail_row_tiles = value; return LG_OK; }
@@ -744,16 +745,16 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
 
     hipLaunchKernelGGL(init_state_kernel, dim3(64), dim3(256), 0, s, B, n0, n1, L, io->num0, io->num1, e->LEN, e->LEN_ORIG, e->LEN_OLD, e->ACTIVE, e->FINAL_LAYER,
                        do_prune ? io->prune0 : nullptr, do_prune ? io->prune1 : nullptr);
-    {
-        PrepArgs p{};
-        p.rs = rs_all; p.n0 = n0; p.n1 = n1; p.kpts0 = io->kpts0; p.kpts1 = io->kpts1; p.size0 = io->size0; p.size1 = io->size1;
-        p.scales0 = io->scales0; p.oris0 = io->oris0; p.scales1 = io->scales1; p.oris1 = io->oris1;
-        p.Wr = e->Wr; p.pos_dim = 2 + 2 * (e->cfg.add_scale_ori ? 1 : 0);
-        p.desc0 = io->desc0; p.desc1 = io->desc1; p.input_dim = e->cfg.input_dim;
-        p.X = e->X; p.Xin = e->XIN; p.cosb = e->COS; p.sinb = e->SIN; p.ind = e->IND; p.bbox = e->BBOX;
-        TRY(prof_begin(e, PC_PREP, s));
-        HIPCHK(launch_prep(p, s));
-    }
+    // prep (+ descriptor copy) as its own launch, or — input_dim == 256, no debug stop — inside the first projection launch (lg_proj.hip proj_first_kernel)
+    const bool fuse_prep = e->fused_prep && e->cfg.input_dim == D && e->debug_stop < 0 && e->tail_timing != 2;
+    PrepArgs p{};
+    p.rs = rs_all; p.n0 = n0; p.n1 = n1; p.kpts0 = io->kpts0; p.kpts1 = io->kpts1; p.size0 = io->size0; p.size1 = io->size1;
+    p.scales0 = io->scales0; p.oris0 = io->oris0; p.scales1 = io->scales1; p.oris1 = io->oris1;
+    p.Wr = e->Wr; p.pos_dim = 2 + 2 * (e->cfg.add_scale_ori ? 1 : 0);
+    p.desc0 = io->desc0; p.desc1 = io->desc1; p.input_dim = e->cfg.input_dim;
+    p.X = e->X; p.Xin = e->XIN; p.cosb = e->COS; p.sinb = e->SIN; p.ind = e->IND; p.bbox = e->BBOX;
+    TRY(prof_begin(e, PC_PREP, s));
+    if (fuse_prep) HIPCHK(launch_prep_bbox(p, s)); else HIPCHK(launch_prep(p, s));
     auto gemm = [&](int epi, const RowSpace& rs, const float* A, int lda, const float* A2, int lda2, int K1, int K,
                     const PackedW& W, const float* bias, int Nout, float* out, int ldo, float scale) -> GemmArgs {
         GemmArgs g{};
@@ -798,7 +799,8 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 ProjArgs pj = make_proj(i, blk);
                 pj.dbg = (e->tail_timing == 2 && blk == 0) ? e->TAILDBG : nullptr;
                 TRY(prof_begin(e, blk == 0 ? PC_GEMM_QKV_SELF : PC_GEMM_QKV_CROSS, s));
-                HIPCHK(launch_proj(prec, ap, pj, s));
+                if (fuse_prep && i == 0 && blk == 0) { pj.rs = rs_all; HIPCHK(launch_proj_first(prec, ap, pj, p, s)); }   // rs_all: what prep covers (pairs with an empty image too)
+                else HIPCHK(launch_proj(prec, ap, pj, s));
                 TRY(prof_end(e, s));
             }
             proj_done = false;

@@ -124,6 +124,12 @@ struct PrepArgs {
     float* bbox;                   // [2B][4] scratch (minx,miny,maxx,maxy) when size is absent
 };
 hipError_t launch_prep(const PrepArgs& a, hipStream_t s);
+hipError_t launch_prep_bbox(const PrepArgs& a, hipStream_t s);   // only the bounding boxes (image_size absent); no-op otherwise
+// The FIRST SelfBlock projection of a forward with the per-keypoint preparation fused in (input_dim == 256): the workgroup builds the rotary rows of its
+// 64 keypoints itself (normalisation + Fourier encoding, written to COS / SIN for the later layers and kept in LDS for its own epilogue), reads the
+// descriptor rows straight from the input tensors (and stores them as the fp32 residual stream X) and fills the index set — one launch and one
+// 64 MB read + write of the descriptors less than prep_kernel + proj_kernel.  `pa` as for launch_prep (X / cosb / sinb / ind are the outputs).
+hipError_t launch_proj_first(int prec, int attn_prec, const ProjArgs& a, const PrepArgs& pa, hipStream_t s);
 
 struct LnGeluArgs { RowSpace rs; const float* h; float* g; const float* gamma; const float* beta; int R; };
 hipError_t launch_ln_gelu(const LnGeluArgs& a, hipStream_t s);

@@ -64,6 +64,10 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
     for (int c = lane * 4; c < a.input_dim; c += 256) *reinterpret_cast<f32x4*>(dst + c) = *reinterpret_cast<const f32x4*>(d + c);
 }
 
+hipError_t launch_prep_bbox(const PrepArgs& a, hipStream_t s) {
+    if (!a.size0 || !a.size1) hipLaunchKernelGGL(bbox_kernel, dim3(2 * a.rs.B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
 hipError_t launch_prep(const PrepArgs& a, hipStream_t s) {
     if (a.input_dim % 4) return hipErrorInvalidValue;
     const int nseg = 2 * a.rs.B;

@@ -421,6 +421,35 @@ def test_fused_next_projection_is_bit_identical(precision):
         assert torch.equal(torch.as_tensor(fused["stop"]), torch.as_tensor(plain["stop"]))
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "fp32", "bf16"])
+def test_fused_prep_is_bit_identical(precision):
+    """The first SelfBlock projection launch also does the per-keypoint preparation (normalisation, Fourier rotary rows, index set, descriptor rows ->
+    residual stream; engine option fused_prep, default on, input_dim == 256): the same expressions in the same order as prep_kernel + proj_kernel, so
+    every output must be BIT-identical with the option off — image_size given and absent (bounding boxes), ragged counts incl. an empty image,
+    scale / orientation inputs (4-D positional encoding), adaptive depth / width."""
+    require_gpu()
+    cases = [("A", dict(depth_confidence=-1, width_confidence=-1), (31, 3, 300, 333), dict()),
+             ("A", dict(depth_confidence=-1, width_confidence=-1), (32, 2, 200, 129), dict(drop_size=True)),
+             ("C", dict(pruning_min_kpts=64), (33, 3, 260, 200), dict(nums=([260, 77, 0], [200, 5, 130]))),
+             ("A", dict(depth_confidence=-1, width_confidence=-1, add_scale_ori=True), (34, 2, 150, 170), dict(sift=True))]
+    for recipe, kw, (seed, B, n, m), opt in cases:
+        sd = synth.make_state_dict(0, recipe=recipe, add_scale_ori=bool(opt.get("sift")))
+        data = gpu_util.to_torch(synth.make_batch(seed, B, n, m, add_scale_ori=bool(opt.get("sift"))))
+        if opt.get("drop_size"):
+            for k in ("image0", "image1"):
+                data[k].pop("image_size")
+        if "nums" in opt:
+            data["image0"]["num_keypoints"] = torch.as_tensor(opt["nums"][0], dtype=torch.int32, device="cuda")
+            data["image1"]["num_keypoints"] = torch.as_tensor(opt["nums"][1], dtype=torch.int32, device="cuda")
+        model = gpu_util.make_model(sd, precision, **kw)
+        on = model(data)
+        model.set_option("fused_prep", 0)
+        off = model(data)
+        for key in ("matches0", "matches1", "matching_scores0", "matching_scores1", "prune0", "prune1"):
+            assert torch.equal(on[key], off[key]), (recipe, key, opt)
+        assert torch.equal(torch.as_tensor(on["stop"]), torch.as_tensor(off["stop"]))
+
+
 @pytest.mark.parametrize("precision", ["f16x3", "f16x3/fp16", "bf16"])
 def test_attention_rows_per_wave_variants_are_equivalent(precision):
     """Engine option attn_rows = 64 / 16 (four / one 16-row query tiles per wave; 256-row workgroup tiles are laid out

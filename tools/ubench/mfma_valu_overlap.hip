@@ -78,6 +78,12 @@ template <int SCALAR> __global__ __launch_bounds__(512) void k(float* out, int i
             for (int i = 0; i < 8; ++i) { if (SCALAR == 2) { v[i][0] = __builtin_amdgcn_exp2f(v[i][0]) ; v[i][1] = __builtin_amdgcn_exp2f(v[i][1]); v[i][0] = __builtin_amdgcn_exp2f(v[i][0]) ; v[i][1] = __builtin_amdgcn_exp2f(v[i][1]); }
               else if (SCALAR == 3) { for (int q = 0; q < 8; ++q) { v[i][0] = __builtin_fmaf(v[i][0], 0.999f, 0.001f); v[i][1] = __builtin_fmaf(v[i][1], 1.001f, -0.001f); } }
               else if (SCALAR == 4) { for (int q = 0; q < 8; ++q) v[i] = v[i] * f32x2{0.999f, 1.001f} + f32x2{0.001f, -0.001f}; }
+              else if (SCALAR == 5) { for (int q = 0; q < 8; ++q) { uint32_t x0 = __builtin_bit_cast(uint32_t, v[i][0]), x1 = __builtin_bit_cast(uint32_t, v[i][1]);   // integer add, 2 VGPR operands
+                  asm volatile("v_add_u32_e32 %0, %0, %1\n\tv_add_u32_e32 %1, %1, %0" : "+v"(x0), "+v"(x1)); v[i][0] = __builtin_bit_cast(float, x0); v[i][1] = __builtin_bit_cast(float, x1); } }
+              else if (SCALAR == 6) { for (int q = 0; q < 8; ++q) { asm volatile("v_fma_f32 %0, %0, %2, 0.5\n\tv_fma_f32 %1, %1, %2, 0.5" : "+v"(v[i][0]), "+v"(v[i][1]) : "s"(0.999f)); } }   // fma, ONE VGPR operand (+ one SGPR, one inline constant: gfx9 reads one scalar per VOP3)
+              else if (SCALAR == 7) { for (int q = 0; q < 8; ++q) { asm volatile("v_fma_f32 %0, %0, %1, %0\n\tv_fma_f32 %1, %1, %0, %1" : "+v"(v[i][0]), "+v"(v[i][1])); } }                               // fma, THREE VGPR operands
+              else if (SCALAR == 8) { for (int q = 0; q < 8; ++q) { uint32_t h; asm volatile("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_fma_mix_f32 %1, %0, -1.0, %1 op_sel_hi:[1,0,0]" : "=&v"(h), "+v"(v[i][0]) : "v"(v[i][1])); } }   // the split's pair
+              else if (SCALAR == 9) { for (int q = 0; q < 8; ++q) { asm volatile("v_max3_f32 %0, %0, %1, %0\n\tv_max3_f32 %1, %1, %0, %1" : "+v"(v[i][0]), "+v"(v[i][1])); } }
               else if (SCALAR) { v[i][0] = gelu_fast1(v[i][0]) + 0.1f; v[i][1] = gelu_fast1(v[i][1]) + 0.1f; } else v[i] = gelu_fast2(v[i]) + 0.1f; }
         }
 #pragma unroll
@@ -106,6 +112,11 @@ int main() {
         { const float a = run<2>(d, iters, 2, viters * 4), b = run<2>(d, iters, 3, viters * 4); printf("v_exp_f32 only   x%d: alone %.3f both %.3f -> overlap %.2f\n", viters * 4, a, b, (tm + a - b) / fminf(tm, a)); }
         { const float a = run<3>(d, iters, 2, viters), b = run<3>(d, iters, 3, viters); printf("v_fma_f32 only   x%d: alone %.3f both %.3f -> overlap %.2f\n", viters, a, b, (tm + a - b) / fminf(tm, a)); }
         { const float a = run<4>(d, iters, 2, viters), b = run<4>(d, iters, 3, viters); printf("v_pk_fma_f32 only x%d: alone %.3f both %.3f -> overlap %.2f\n", viters, a, b, (tm + a - b) / fminf(tm, a)); }
+        { const float a = run<5>(d, iters, 2, viters), b = run<5>(d, iters, 3, viters); printf("v_add_u32 (2 VGPR) x%d: alone %.3f both %.3f -> overlap %.2f\n", viters, a, b, (tm + a - b) / fminf(tm, a)); }
+        { const float a = run<6>(d, iters, 2, viters), b = run<6>(d, iters, 3, viters); printf("v_fma_f32 1 VGPR + SGPR + const x%d: alone %.3f both %.3f -> overlap %.2f\n", viters, a, b, (tm + a - b) / fminf(tm, a)); }
+        { const float a = run<7>(d, iters, 2, viters), b = run<7>(d, iters, 3, viters); printf("v_fma_f32 3 VGPR x%d: alone %.3f both %.3f -> overlap %.2f\n", viters, a, b, (tm + a - b) / fminf(tm, a)); }
+        { const float a = run<8>(d, iters, 2, viters), b = run<8>(d, iters, 3, viters); printf("v_cvt_pk_f16_f32 + v_fma_mix_f32 x%d: alone %.3f both %.3f -> overlap %.2f\n", viters, a, b, (tm + a - b) / fminf(tm, a)); }
+        { const float a = run<9>(d, iters, 2, viters), b = run<9>(d, iters, 3, viters); printf("v_max3_f32 x%d: alone %.3f both %.3f -> overlap %.2f\n", viters, a, b, (tm + a - b) / fminf(tm, a)); }
         const float tv = run<0>(d, iters, 2, viters), tb = run<0>(d, iters, 3, viters);
         printf("packed VALU iters %d: VALU alone %.3f ms, both %.3f ms  (sum %.3f, max %.3f) -> overlap efficiency %.2f\n", viters, tv, tb, tm + tv, fmaxf(tm, tv), (tm + tv - tb) / fminf(tm, tv));
     }

@@ -21,3 +21,6 @@ echo "best variant: $BEST" | tee -a $O/ab_cfg2.log
 for v in base $BEST; do echo "== $v"; LIGHTGLUE_AMD_LIB=$(lib $v) timeout 120 python tools/tail_timing.py f16x3 5 2>&1 | grep -E "phaseA|LN|GELU0|phaseB|epilogue|total"; done | tee $O/stamps.log
 LIGHTGLUE_AMD_LIB=$(lib $BEST) timeout 150 python -m pytest tests/test_gpu_parity.py -q -x -n 4 -k "default_precision_parity or pipeline_stages_layer0 or fused_next_projection or tail_row_tile" > $O/tests_best.log 2>&1; tail -2 $O/tests_best.log
 for v in base $BEST; do echo "== $v"; LIGHTGLUE_AMD_LIB=$(lib $v) timeout 90 python tools/bench_configs.py "#3' " "#5' " 2>&1 | grep "^| #"; done | tee $O/ab_configs.log
+# compaction with two workgroups per CU (tools/experiments/compact_two_per_cu.patch): adaptive configs, two rounds, then the adaptive fixtures with it
+for round in 1 2; do for v in base c2; do echo "== $v"; LIGHTGLUE_AMD_LIB=$(lib $v) timeout 90 python tools/bench_configs.py "#3' " "#3b" "#5' " 2>&1 | grep "^| #"; done; done | tee $O/ab_compaction.log
+LIGHTGLUE_AMD_LIB=$(lib c2) timeout 150 python -m pytest tests/test_gpu_parity.py -q -x -n 4 -k "adaptive or pruned or ragged" > $O/tests_c2.log 2>&1; tail -2 $O/tests_c2.log

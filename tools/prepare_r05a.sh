@@ -10,4 +10,7 @@ tools/build_variant.sh gsi3 -DLG_GELU_SCALAR=1 -DLG_GELU_INTERLEAVE=3 | tail -1
 tools/build_variant.sh gi2  -DLG_GELU_INTERLEAVE=2 | tail -1
 tools/build_variant.sh go   -DLG_GELU_OFFSET=1 | tail -1
 tools/build_variant.sh gso  -DLG_GELU_SCALAR=1 -DLG_GELU_OFFSET=1 | tail -1
+unset LG_VARIANT_SRC
+tools/make_variant_src.sh r05c tools/experiments/compact_two_per_cu.patch | tail -1
+LG_VARIANT_SRC=$PWD/build_variants/src_r05c tools/build_variant.sh c2 | tail -1
 rm -rf build_variants/obj_*

@@ -42,10 +42,14 @@
 //            next layer's SelfBlock) runs here: saves that kernel's launch, its x-tile read + conversion and a grid drain.
 //            NEXT == 3: the LAST tail of a fixed-depth forward runs the final projection of the log assignment instead.
 #include "lg_proj_body.h"
+#include <type_traits>
 
 namespace lg {
 
 constexpr int TTHREADS = 512;
+#ifndef LG_TAIL_CTX_DMA
+#define LG_TAIL_CTX_DMA 1   // ctx half of the activation tile by piecewise LDS-DMA under the x half's MFMAs (A/B switch; 0 = the round-4 register path)
+#endif
 
 template <int PREC> struct TT;
 template <> struct TT<PREC_F32> { typedef TagF32 Tag; static constexpr int KE = 32, NPART = 1; };
@@ -206,12 +210,13 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             for (int p = 0; p < NPART; ++p)
                 af[mt][p] = *reinterpret_cast<const u32x4*>(tile + p * G_PLANE + lds_off<128>(mt * 16 + lr, (kc & 1) * 4 + g));
     };
-    auto mma_A = [&](const u32x4 (&af)[MT][NPART], const u32x4 (&b)[4][NPART]) {
+    auto mma_A_rows = [&](const u32x4 (&af)[MT][NPART], const u32x4 (&b)[4][NPART], int mt0, int mt1) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = mt0; mt < mt1; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) tail_mma<PREC>(acc[mt][nt], b[nt], af[mt]);
     };
+    auto mma_A = [&](const u32x4 (&af)[MT][NPART], const u32x4 (&b)[4][NPART]) { mma_A_rows(af, b, 0, MT); };
     load_half(0);
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i) load_b_A(bf[i], i);
@@ -222,16 +227,47 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     // to here and waits for these loads in front of the loop.  Forcing the conversion back behind the loop — registers laundered through an empty
     // asm — and / or requesting the ctx rows together with the x rows measured -1.4 % / +-0: the in-order load counter makes chunk 1's weight
     // fragments wait for the ctx rows either way, and the converted planes are 16 registers instead of 32 through the loop.  LAB_NOTES.md.)
-    load_half(1);
+    // CTX_DMA (round 5; split-f16, 64-row tiles): the ctx half is NOT requested here.  Stamps inside phase A (profiles/r05c_phaseA_diag.log) showed
+    // what the round-4 form costs: x published 9.7k cycles after the kernel starts, then 3.7k more in front of the loop until the 64 KB of ctx rows have
+    // arrived — a CU pulls HBM misses at ~10 B/clk whatever the other CUs do (profiles/r05d_stagger_diag.log) — while both MFMA loops run at 80 - 90 % of the
+    // matrix pipe.  Now every wave moves ITS OWN 8 rows of ctx (8 KB) by LDS-DMA, one 1 KB piece per chunk of the x half, issued BEHIND that chunk's weight
+    // fragments (placement: see the loop).  The
+    // pieces land as fp32 in the wave's own eight 1 KB pieces of K-stages 4..7 (its rows of the hi and of the lo plane: exactly the bytes its operand rows
+    // will occupy), so the conversion at the half boundary is wave-private and IN PLACE: read all 32 floats per lane, then write hi / lo — no staging
+    // area, no staging registers through the loop (32 VGPRs), one barrier as before.  The DMA is the inline-asm form (lg_common.h lds_dma16): through the
+    // builtin hipcc orders every later ds_read behind it with vmcnt(0) lgkmcnt(0) — a full round trip in front of every chunk (round-5 ISA).
+    constexpr bool CTX_DMA = LG_TAIL_CTX_DMA && PREC == PREC_F16X3 && MT == 4;
+    if constexpr (!CTX_DMA) load_half(1);
     __builtin_amdgcn_sched_barrier(0);
     constexpr int HC = NKC / 2;         // k-chunks per half
+    // piece j = (K-stage 4 + (j >> 1), row group j & 1): lane l fetches 16 bytes of row 8w + 4 (j & 1) + (l >> 4), columns 64 (j >> 1) + 4 (l & 15) ..
+    const float* ctx_lane = a.CTX + (long long)(t.grow0 + 8 * w + (lane >> 4)) * 256 + (lane & 15) * 4;
+    auto ctx_dma = [&](int s, int q) {
+        if constexpr (CTX_DMA) lds_dma16(ctx_lane + q * 1024 + s * 64, smem + (HS + s) * TILE + q * G_PLANE + w * 1024);
+    };
+    auto ctx_convert_in_place = [&]() {       // lane l: row 8w + (l >> 3), eight floats 8 (l & 7) .. of each of the four K-stages
+        const int r8 = lane >> 3, slot = lane & 7;
+        const char* src = smem + HS * TILE + (r8 >> 2) * G_PLANE + w * 1024 + 256 * (r8 & 3) + 32 * slot;
+        f32x4 st[4][2];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) { st[s2][0] = *reinterpret_cast<const f32x4*>(src + s2 * TILE); st[s2][1] = *reinterpret_cast<const f32x4*>(src + s2 * TILE + 16); }
+        __builtin_amdgcn_sched_barrier(0);    // every read of the wave's staging bytes is issued before the first write (LDS executes a wave's accesses in order)
+        char* dst = smem + HS * TILE + lds_off<128>(8 * w + r8, slot);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            u32x4 hi, lo;
+            split8<Tag>(st[s2][0], st[s2][1], hi, lo);
+            *reinterpret_cast<u32x4*>(dst + s2 * TILE) = hi;
+            *reinterpret_cast<u32x4*>(dst + s2 * TILE + G_PLANE) = lo;
+        }
+    };
     // The activation fragments of chunk kc + 1 are read from LDS BEFORE the MFMAs of chunk kc (two register sets): with
     // the wave index provably uniform (SGPR address parts) the kernel has the 32 VGPRs for it, and the ~200-cycle LDS round
     // trip at the head of every chunk — which both waves of a SIMD hit at the same time — disappears.  The prefetch stays
     // inside a half (the other half is not in LDS yet); a half's first chunk reads its own.
     u32x4 afr[2][MT][NPART];
-#pragma unroll 1
-    for (int hf = 0; hf < 2; ++hf) {
+    auto run_half = [&](auto HF) {            // two copies of the loop (no runtime branch around the DMA issue: hipcc merges wait states conservatively at joins)
+        constexpr int hf = decltype(HF)::value;
         read_af(afr[0], hf * HC);
 #pragma unroll 1
         for (int c0 = 0; c0 < HC; c0 += NBUF) {
@@ -241,15 +277,34 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
                 load_b_A(bf[(i + NBUF - 1) % NBUF], kc + NBUF - 1 < NKC ? kc + NBUF - 1 : NKC - 1);
                 read_af(afr[(i + 1) & 1], c0 + i + 1 < HC ? kc + 1 : kc);
                 __builtin_amdgcn_sched_barrier(0);
-                mma_A(afr[i & 1], bf[i]);
+                if constexpr (CTX_DMA && hf == 0) {
+                    // The piece is issued BEHIND the chunk's last fragment wait (all 8 fragments are consumed by the first row tile's MFMAs).  hipcc does not
+                    // count the asm DMA: its waits vmcnt(15 - f) for fragment f of this chunk are one too strict from here on, i.e. they also cover the
+                    // OLDEST operation behind that fragment — which with this placement is the piece of the PREVIOUS chunk (most of a chunk old), never a
+                    // fragment or a piece that was just issued (any earlier placement makes every chunk wait for a round trip; ISA-checked).
+                    mma_A_rows(afr[i & 1], bf[i], 0, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ctx_dma((c0 + i) >> 1, (c0 + i) & 1);          // HC = 8 chunks = 8 pieces
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_A_rows(afr[i & 1], bf[i], 1, MT);
+                } else {
+                    mma_A(afr[i & 1], bf[i]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (hf == 0) {
-            store_half(1);
-            __syncthreads();
-        }
+    };
+    run_half(std::integral_constant<int, 0>{});
+    if constexpr (CTX_DMA) {
+        static_assert(!CTX_DMA || HC == 8, "one ctx piece per chunk of the x half");
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces have landed (the last one was issued a chunk ago, behind the fragments of chunk 8)
+        __builtin_amdgcn_sched_barrier(0);
+        ctx_convert_in_place();
+    } else {
+        store_half(1);
     }
+    __syncthreads();
+    run_half(std::integral_constant<int, 1>{});
     stamp(1);
     // ------------------------------------------------------------------ LayerNorm(512) (the bias is already in the accumulators)
     // acc[mt][nt][r] = h[row mt*16 + lr][hidden (w + 8 nt)*16 + 4g + r]

@@ -43,6 +43,16 @@ PAIRS_PER_GPU = 32
 D = 256
 L = 9
 
+# BASELINE.json `configs` (index = the --config number; 1 is the reference's own CPU case, timed in cpu_baseline.cfg1_*).  Per GPU and step:
+# `pairs` image pairs of n x m keypoints with dim-d descriptors; adaptive = the reference's defaults depth_confidence 0.95 / width_confidence 0.99
+# (recipe C weights: pairs stop at mixed depths and prune), else both off.  The default (2) is the configuration the metric is quoted on.
+CONFIGS = {
+    2: dict(label="BASELINE configs[1]: SuperPoint 256-d, N=M=1024, 9 layers, pruning OFF, batch=32 per GPU", pairs=PAIRS_PER_GPU, n=N_KPTS, m=N_KPTS, dim=256, recipe="A", wseed=0, adaptive=False),
+    3: dict(label="BASELINE configs[2]: SuperPoint 256-d, N=M=2048, depth_confidence=0.95 width_confidence=0.99 (adaptive pruning ON), batch=16 per GPU", pairs=16, n=2048, m=2048, dim=256, recipe="C", wseed=0, adaptive=True),
+    4: dict(label="BASELINE configs[3]: DISK 128-d, N=M=4096, 9 layers, pruning OFF, batch=32 per GPU (256 pairs pair-sharded over 8 GPUs, RCCL gather)", pairs=32, n=4096, m=4096, dim=128, recipe="A", wseed=0, adaptive=False),
+    5: dict(label="BASELINE configs[4]: ALIKED 128-d, asymmetric N=2048 M=512, pruning ON, batch=64 per GPU (ragged / compaction stress)", pairs=64, n=2048, m=512, dim=128, recipe="C", wseed=2, adaptive=True),
+}
+
 # ---- algorithmic FLOPs (2 per MAC), SURVEY.md §8d.  Per launch of each kernel class over `pairs` pairs.
 def flops_per_launch(pairs: int, n: int, m: int):
     pts = pairs * (n + m)
@@ -154,82 +164,107 @@ def _port_over_reference(n, threads):
     return row["N=512" if n <= 768 else "N=1024"]
 
 
-def cpu_baseline(sd, n, m, gpu_out=None, budget_s=20.0, max_pairs=32, recipe="A"):
-    """CPU leg (rank 0, N = 1 only; ~20-30 s in total).  The port of the reference's CPU fp32 path (oracle/, torch-kernel backend:
+def cpu_baseline(sd, n, m, gpu_out=None, budget_s=24.0, max_pairs=32, recipe="A", conf_kw=None, dim=256):
+    """CPU leg (rank 0, N = 1 only; ~25-35 s in total).  The port of the reference's CPU fp32 path (oracle/, torch-kernel backend:
     the same restatement on the ATen CPU kernels the reference computes with) is timed on pairs of the SAME seeded batch the GPU
-    matched (pair seeds 1, 2, ...), so the same calls also CHECK the GPU result (returned as the second value).  When /root/reference is mounted (build container) the real reference is timed beside it;
-    on the GPU box it is not, and the port's measured slowdown against the reference is reported instead."""
+    matched (pair seeds 1, 2, ...), so the same calls also CHECK the GPU result (returned as the second value).
+    Method: the thread count is the fastest of 8 / 16 / 32 on one probe pair; the process is pinned to that many
+    distinct cores for the timed part; the same k pairs are timed THREE times and `value` is the median rate; the 1-thread rate is
+    reported beside it.  When /root/reference is mounted (build container) the real reference is timed too; on the GPU box it is not,
+    and the port's measured slowdown against the reference is reported instead."""
     from oracle import lightglue_oracle as O  # test/baseline infrastructure only: the checker and the timed baseline
 
     from contextlib import contextmanager
 
     @contextmanager
-    def threadpool_limits(limits):   # intra-op threads of torch's CPU kernels (the timed port runs on them)
+    def threadpool_limits(limits):   # intra-op threads of torch's CPU kernels (the timed port runs on them), pinned to `limits` cores
         old = torch.get_num_threads()
+        aff = None
+        try:
+            aff = os.sched_getaffinity(0)
+            cores = sorted(aff)[:limits]          # logical CPUs i and i + ncpu / 2 are SMT siblings on the pool's EPYCs: the first ids are distinct cores
+            if len(cores) == limits:
+                os.sched_setaffinity(0, cores)
+        except (AttributeError, OSError):
+            aff = None
         torch.set_num_threads(limits)
         try:
             yield
         finally:
             torch.set_num_threads(old)
+            if aff is not None:
+                try:
+                    os.sched_setaffinity(0, aff)
+                except OSError:
+                    pass
 
-    conf = O.make_conf(depth_confidence=-1, width_confidence=-1)
+    conf = O.make_conf(**(conf_kw if conf_kw is not None else dict(depth_confidence=-1, width_confidence=-1)))
+    kw = batch_kwargs(recipe)
     ncpu = os.cpu_count() or 1
-    # pick the thread count that is fastest on this host (more threads is not monotonically better
-    # for 1024x256-sized GEMMs); one untimed probe pair per candidate
     best, best_t = 1, float("inf")
-    probe = synthetic.make_batch(999, 1, n, m)
-    for th in sorted({1, min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu)}):
+    probe = synthetic.make_batch(999, 1, n, m, dim, **kw)
+    for th in sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu)}):
         with threadpool_limits(limits=th):
             t = float("inf")
             for _ in range(2):   # the first call at a new thread count also pays the pool's start-up
                 t0 = time.perf_counter(); timed_port_forward(sd, conf, probe, th); t = min(t, time.perf_counter() - t0)
         if t < best_t:
             best, best_t = th, t
-    done, t0 = 0, time.perf_counter()
-    refs = []
+    # k pairs per round so that three rounds fit the budget; at least one
+    k = int(max(1, min(max_pairs, budget_s / 3.0 / max(best_t, 1e-3))))
+    batches = [synthetic.make_batch(1 + i, 1, n, m, dim, **kw) for i in range(k)]      # == pairs 0..k-1 of rank 0's GPU batch
+    rates, refs = [], []
     with threadpool_limits(limits=best):
-        while done < max_pairs:
-            data = synthetic.make_batch(1 + done, 1, n, m, **batch_kwargs(recipe))      # == pair `done` of rank 0's GPU batch
-            refs.append(timed_port_forward(sd, conf, data, best))
-            done += 1
-            if time.perf_counter() - t0 > budget_s:
-                break
-    dt = time.perf_counter() - t0
-    # SURVEY §8d: cfg #1 (N=M=512, B=1, fp32) with 1 thread and with the best thread count
+        for rnd in range(3):
+            t0 = time.perf_counter()
+            out = [timed_port_forward(sd, conf, d, best) for d in batches]
+            rates.append(k / (time.perf_counter() - t0))
+            if rnd == 0:
+                refs = out
+    value = float(np.median(rates))
+    one_thread = None
+    if best_t * best < 25.0:   # (skipped for the big shapes: one thread would take minutes at N = 4096)
+        with threadpool_limits(limits=1):
+            t0 = time.perf_counter(); timed_port_forward(sd, conf, batches[0], 1); one_thread = 1.0 / (time.perf_counter() - t0)
+    # SURVEY §8d: cfg #1 (N=M=512, B=1, fp32, SuperPoint dim, non-adaptive) with 1 thread and with the chosen thread count
     cfg1 = {}
-    d512 = synthetic.make_batch(1, 1, 512, 512)
-    for th in sorted({1, best}):
-        with threadpool_limits(limits=th):
-            timed_port_forward(sd, conf, d512, th)
-            t1 = time.perf_counter(); timed_port_forward(sd, conf, d512, th); timed_port_forward(sd, conf, d512, th)
-            cfg1[f"{th} thread(s)"] = round(2.0 / (time.perf_counter() - t1), 3)
-    res = {"value": done / dt, "unit": "image-pairs/s", "cores": best, "kind": "port",
-           "sample": f"{done} pair(s) N=M={n} of the benchmark's own batch, 9 layers, fp32 port of the reference CPU path (oracle/ on torch's CPU kernels), {dt:.1f}s, "
-                     f"{best} thread(s) (fastest of 1/8/16/32/64 on {ncpu} logical cores)",
+    if dim == 256:
+        conf1 = O.make_conf(depth_confidence=-1, width_confidence=-1)
+        d512 = synthetic.make_batch(1, 1, 512, 512)
+        for th in sorted({1, best}):
+            with threadpool_limits(limits=th):
+                timed_port_forward(sd, conf1, d512, th)
+                t1 = time.perf_counter(); timed_port_forward(sd, conf1, d512, th); timed_port_forward(sd, conf1, d512, th)
+                cfg1[f"{th} thread(s)"] = round(2.0 / (time.perf_counter() - t1), 3)
+    res = {"value": value, "unit": "image-pairs/s", "cores": best, "kind": "port",
+           "sample": f"{k} pair(s) N={n} M={m} of the benchmark's own batch timed 3 times (median), 9 layers, fp32 port of the reference CPU path (oracle/ on torch's CPU kernels), "
+                     f"{best} thread(s) pinned to {best} cores (fastest of 8/16/32 on {ncpu} logical cores)",
+           "rounds_pairs_per_s": [round(r, 3) for r in rates], "one_thread_pairs_per_s": None if one_thread is None else round(one_thread, 3),
            "cpu_model": _cpu_model(), "logical_cores": ncpu,
            "cfg1_n512_b1_pairs_per_s": cfg1,
            "port_over_reference_time_ratio": PORT_OVER_REFERENCE_TIME,
            "port_over_reference_source": "profiles/r03_cpu_reference.md (tools/cpu_reference_table.py: the unmodified reference and this port timed side by side in the build container)",
            # what the REAL reference would do on these cores, by the measured ratio (the GPU box has no /root/reference)
-           "reference_estimate_pairs_per_s": round(done / dt * _port_over_reference(n, best), 3),
+           "reference_estimate_pairs_per_s": round(value * _port_over_reference(n, best), 3),
            # the ratio behind the estimate was measured at 1 and 8 threads on the build container's Xeon; here it is applied to `cores`
            # threads of this box's CPU — outside the thread count and the CPU it was measured on (VERDICT r03 weak 9).  The port's own
-           # number (`value`) is the measured one; between boxes of the pool it has ranged 4.05 - 6.43 pairs/s (host load, not the code)
+           # number (`value`) is the measured one
            "reference_estimate_note": f"ratio measured at 1 / 8 threads on an 8-vCPU Xeon (build container), applied to {best} thread(s) of {_cpu_model()}: an extrapolation, not a measurement"}
-    if REFERENCE_FILE.exists():   # build container only: time the real thing beside the port
+    nonadaptive = conf_kw is None or (conf_kw.get("depth_confidence", 1) <= 0 and conf_kw.get("width_confidence", 1) <= 0)
+    if REFERENCE_FILE.exists() and dim == 256 and n == m and nonadaptive:   # build container only: time the real thing beside the port
         try:
-            ref_t = {f"N={k} {th} thread(s)": round(1.0 / _time_reference(sd, k, th, reps=3), 3) for k in (512, n) for th in sorted({1, min(8, ncpu)})}
+            ref_t = {f"N={kk} {th} thread(s)": round(1.0 / _time_reference(sd, kk, th, reps=3), 3) for kk in (512, n) for th in sorted({1, min(8, ncpu)})}
             res["reference_pairs_per_s"] = ref_t
             res["kind"] = "reference"
-            res["value"] = max(v for k, v in ref_t.items() if k.startswith(f"N={n} "))
+            res["value"] = max(v for kk, v in ref_t.items() if kk.startswith(f"N={n} "))
             res["cores"] = min(8, ncpu)
             res["sample"] = f"unmodified reference (lightglue.py loaded standalone), CPU fp32, B=1, N=M={n}, 2 warm-up + 3 timed forwards; port timings kept in port_pairs_per_s"
-            res["port_pairs_per_s"] = done / dt
+            res["port_pairs_per_s"] = value
         except Exception as exc:  # pragma: no cover
             res["reference_error"] = repr(exc)[:200]
     parity = None
     if gpu_out is not None:
-        parity = parity_block(gpu_out, refs, n, m, source=f"oracle (port of the reference CPU path on torch CPU kernels, fp32) on pairs 0..{done - 1} of the timed batch")
+        parity = parity_block(gpu_out, refs, n, m, source=f"oracle (port of the reference CPU path on torch CPU kernels, fp32) on pairs 0..{k - 1} of the timed batch")
     return res, parity
 
 
@@ -278,11 +313,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16", "fp16", "fp32"])
     ap.add_argument("--attention", default=None, choices=["fp16"], help="with --precision f16x3: the single-plane f16 attention (fast opt-in, outside the bar for sharp attention)")
-    ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per step")
-    ap.add_argument("--kpts", type=int, default=N_KPTS)
-    ap.add_argument("--recipe", default="A", choices=["A", "D"], help="seeded weights / inputs: A (SURVEY 8c, the headline) or D (trained-model "
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config number (1-based as in DESIGN.md): 2 = the headline (default), 3 = N=M=2048 adaptive, "
+                    "4 = DISK 128-d N=M=4096 (the pair-sharded 8-GPU config: use with --gpus N), 5 = ALIKED 128-d 2048x512 adaptive")
+    ap.add_argument("--pairs", type=int, default=None, help="pairs per GPU per step (default: the config's)")
+    ap.add_argument("--kpts", type=int, default=None, help="keypoints per image, N = M (default: the config's)")
+    ap.add_argument("--recipe", default=None, choices=["A", "C", "D"], help="seeded weights / inputs (default: the config's): A (SURVEY 8c, the headline), C (adaptive: mixed stop depths) or D (trained-model "
                     "statistics: attention logit spread 25, LayerNorm gains in [0.5, 4], residual rms ~27, descriptor norms in [0.5, 3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather-probe", action="store_true", help="one GPU: skip the K extra steps that measure what the (world-of-one) side-stream result gather costs a step")
     ap.add_argument("--no-pipeline", action="store_true", help="one GPU: synchronous forward per step (no deferred output assembly)")
     ap.add_argument("--no-calibration", action="store_true", help="skip the 25 ms dense-MFMA spin that measures what the box sustains (profiling runs)")
     ap.add_argument("--no-fuse-next", action="store_true", help="run the q/k/v projections as their own kernels instead of inside the previous block's tail kernel")
@@ -329,12 +367,18 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    n = m = args.kpts
-    B = args.pairs
-    sd = synthetic.make_state_dict(0, recipe=args.recipe)
-    model = LightGlue(features=None, depth_confidence=-1, width_confidence=-1, precision=args.precision, attention_precision=args.attention).eval()
+    cfg = CONFIGS[args.config]
+    n, m = (args.kpts, args.kpts) if args.kpts else (cfg["n"], cfg["m"])
+    B = args.pairs or cfg["pairs"]
+    dim, adaptive = cfg["dim"], cfg["adaptive"]
+    args.recipe = args.recipe or cfg["recipe"]
+    conf_kw = ({} if adaptive else dict(depth_confidence=-1, width_confidence=-1))
+    if dim != 256:
+        conf_kw["input_dim"] = dim
+    sd = synthetic.make_state_dict(cfg["wseed"], recipe=args.recipe, input_dim=dim)
+    model = LightGlue(features=None, precision=args.precision, attention_precision=args.attention, **conf_kw).eval()
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
-    data_np = synthetic.make_batch(1 + rank * B, B, n, m, **batch_kwargs(args.recipe))
+    data_np = synthetic.make_batch(1 + rank * B, B, n, m, dim, **batch_kwargs(args.recipe))
     data = {k: {kk: torch.from_numpy(vv).to(dev) for kk, vv in v.items()} for k, v in data_np.items()}
     model.reserve(B, n, m, dev)
     for kv in os.environ.get("LG_BENCH_OPTS", "").split():   # A/B of engine options in one box, e.g. LG_BENCH_OPTS="tail_row_tiles=2 attn_rows=64"
@@ -457,6 +501,37 @@ def main():
         torch.cuda.synchronize(dev)
         sync_value = B * args.steps / (time.perf_counter() - ts)
         del out_sync
+    gather_probe = None
+    if world == 1 and not args.no_gather_probe:
+        # what the pair-sharded path's result gather costs a step when it runs beside the next forward: the same K steps through
+        # PairShardedMatcher in a world of ONE over RCCL — engine-packed wire rows, all_gather_into_tensor on the side stream behind an event, unpack
+        # kernel — against the plain pipelined loop above.  At N > 1 the collective is the same call with N - 1 more peers on the xGMI ring.
+        try:
+            import socket
+            import torch.distributed as dist
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)); os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            one = PairShardedMatcher(model, always_gather=True)
+            pend = None
+            for _ in range(3):
+                prev, pend = pend, one.issue_local(data, B)
+                if prev is not None: prev.wait()
+            pend.wait(); torch.cuda.synchronize(dev)
+            tg = time.perf_counter(); pend = None
+            for _ in range(args.steps):
+                prev, pend = pend, one.issue_local(data, B)
+                if prev is not None: prev.wait()
+            g_out = pend.wait(); torch.cuda.synchronize(dev)
+            g_ms = (time.perf_counter() - tg) / args.steps * 1e3
+            same = bool(torch.equal(g_out["matches0"], out["matches0"])) if "matches0" in out else None
+            gather_probe = {"ms_per_step_with_world1_gather": g_ms, "ms_per_step_plain": dt / args.steps * 1e3, "delta_ms": g_ms - dt / args.steps * 1e3,
+                            "gather_bytes": int(B * (2 * n + 2 * m + 1) * 4), "matches_equal_plain_loop": same,
+                            "what": "K steps through PairShardedMatcher(always_gather) in a world of one over RCCL: engine-packed wire rows, all_gather_into_tensor on a side stream under the next forward, lg_unpack_wire"}
+            dist.destroy_process_group()
+        except Exception as exc:   # the probe must never cost the bench line
+            gather_probe = {"error": repr(exc)[:300]}
 
     if rank == 0:
         total_pairs = B * world * args.steps
@@ -489,7 +564,8 @@ def main():
         mfma_per_mac_attn = 3 if (args.precision == "f16x3" and not args.attention) else 1
         mfma_per_mac_linear = (3 if not args.attention else round((3 * 393216 + 2 * 163840) / 557056, 3)) if args.precision == "f16x3" else 1
         res = {
-            "metric": "image-pairs/s at N=M=1024, 9 layers; match-index parity vs ref",
+            "metric": ("image-pairs/s at N=M=1024, 9 layers; match-index parity vs ref" if args.config == 2 else
+                       f"image-pairs/s at N={n} M={m}, 9 layers ({'adaptive depth/width' if adaptive else 'pruning off'}, {dim}-d descriptors); match-index parity vs ref"),
             "value": value,
             "unit": "image-pairs/s",
             "n_gpus": world,
@@ -503,11 +579,13 @@ def main():
             # product) is WIDER than the bf16 BASELINE cfg #2 names, at the same storage width and MFMA rate per instruction
             "dtype": {"f16x3": "f16", "bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": f"SuperPoint-dim 256-d descriptors, N=M={n}, 9 layers, pruning/early-stop OFF, batch={B} pairs per GPU, "
-                                   f"seeded random weights (recipe {args.recipe}{', trained-model statistics' if args.recipe == 'D' else ''}), precision={args.precision}"
+            "config": {"baseline_config": cfg["label"] if (B, n, m) == (cfg["pairs"], cfg["n"], cfg["m"]) else f"{cfg['label']} — with --pairs / --kpts overrides: batch={B}, N={n}, M={m}",
+                       "workload": (f"SuperPoint-dim 256-d descriptors, N=M={n}, 9 layers, pruning/early-stop OFF, batch={B} pairs per GPU, " if args.config == 2 else
+                                    f"{dim}-d descriptors, N={n} M={m}, 9 layers, {'depth_confidence=0.95 width_confidence=0.99 (early stop + point pruning ON, every pair on its own)' if adaptive else 'pruning/early-stop OFF'}, batch={B} pairs per GPU, ")
+                                   + f"seeded random weights (recipe {args.recipe}{', trained-model statistics' if args.recipe == 'D' else ''}), precision={args.precision}"
                                    + (" (split-f16 operands, 3 MFMAs per product, for every contraction incl. q k^T and P V; fp32 accumulate / residual / softmax)" if args.precision == "f16x3" and not args.attention else "")
                                    + (", attention_precision=fp16 (single-plane f16 attention: the fast opt-in, outside the 1e-3 bar for sharp attention)" if args.attention else ""),
-                       "pairs_per_gpu": B, "keypoints": n, "parallelism": f"pair-sharded dp{world}",
+                       "pairs_per_gpu": B, "keypoints": n, "keypoints1": m, "descriptor_dim": dim, "parallelism": f"pair-sharded dp{world}",
                        "host_pipelining": ("result gather of step i overlaps the forward of step i+1" if world > 1 else
                                            "synchronous forward per step" if args.no_pipeline else
                                            "output assembly (the forward's one host sync) of step i overlaps the forward of step i+1; all K outputs are built inside the timed region")},
@@ -517,7 +595,8 @@ def main():
                          "sustained_peak": sustained_tflops, "frac_of_sustained": (achieved / sustained_tflops if sustained_tflops else None),
                          # matrix-core work actually ISSUED per second: the split-f16 products cost 3 MFMAs per algorithmic MAC
                          "mfma_per_mac": mfma_per_mac_linear, "issued_tflops": achieved * mfma_per_mac_linear,
-                         "note": "algorithmic FLOPs (2/MAC) of one launch / HIP-event launch duration; split f16 issues 3 MFMAs per algorithmic MAC.  "
+                         "note": ("ADAPTIVE config: pairs stop early and rows are pruned during the forward, so the FLOPs of the full N x M shape charged to every launch are an UPPER bound (achieved / frac overstate).  " if adaptive else "")
+                                 + "algorithmic FLOPs (2/MAC) of one launch / HIP-event launch duration; split f16 issues 3 MFMAs per algorithmic MAC.  "
                                  "peak = nominal dense bf16 / f16 (2.4 GHz); sustained_peak = what a dense bf16 MFMA spin "
                                  "reaches on THIS box right before the timed region (power-managed clock, see effective_mfma_clock_mhz)"},
             # the HBM-bound stage of the path: dual log-softmax + argmax sweeps over the similarity matrix
@@ -536,6 +615,10 @@ def main():
             "kernel_ms_per_step": kernel_ms,
             "kernel_ms_per_step_source": ("HIP events around every launch during the warm-up steps; the roofline kernel's entry and "
                                           "avg_launch_ms come from events inside the timed region") if warm_prof else "HIP events inside the timed region",
+            #  class attribution under fusion: what each event class brackets in the product configuration
+            "kernel_ms_class_notes": {"prep": "input_dim 256 (fused_prep): only the bounding-box / state kernels — normalisation, rotary rows, index set and the descriptor copy run inside the FIRST gemm_qkv_self launch (proj_first_kernel), whose time and bytes (1 KB read + 1.3 KB write per keypoint) are in gemm_qkv_self",
+                                      "fused_tail": "tail + the next block's q/k/v projection (+ the final projection in the last launch at fixed depth)",
+                                      "gemm_qkv_self": "the first projection only (later ones run inside fused_tail) unless pruning forces standalone projections"},
             "gpu_ms_per_step_sum": round(sum(kernel_ms.values()), 3),
             "gpu_ms_per_step_sum_note": "sum of the per-class event times of the WARM-UP steps (each launch bracketed by its own event pair, ~90 pairs per step): an upper bound that is not additive with ms_per_step, which is the un-instrumented timed region",
             "algorithmic_tflops": value * flops_per_pair(n, m) / 1e12,
@@ -545,13 +628,14 @@ def main():
             "matches_per_pair": float(np.mean([(o > -1).sum().item() for o in out["matches0"]])) if "matches0" in out else None,
             "value_synchronous_forward": sync_value,   # pairs/s with model(data) per step (host sync inside every forward), N = 1 only
             "rccl": rccl,
+            "gather_probe_one_gpu": gather_probe,
         }
         # match-index parity of the batch that was just timed (rank 0's pairs): against the reference's own fixture for the
         # first 4 pairs and against the oracle on the pairs the CPU leg runs anyway
         default_weights = args.precision in ("f16x3", "fp32")
         res["parity"] = golden_parity(out, n, B, args.recipe) if default_weights else None
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"], res["parity_oracle"] = cpu_baseline(sd, n, m, gpu_out=out, recipe=args.recipe)
+            res["cpu_baseline"], res["parity_oracle"] = cpu_baseline(sd, n, m, gpu_out=out, recipe=args.recipe, conf_kw={k: v for k, v in conf_kw.items() if k != "input_dim"}, dim=dim)
         json_out.write(json.dumps(res) + "\n")
         json_out.flush()
     if world > 1:

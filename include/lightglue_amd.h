@@ -36,6 +36,10 @@ enum {
 #define LG_ERR_INVALID 1   /* bad argument (the Python shim raises AssertionError/ValueError)      */
 #define LG_ERR_HIP 2       /* a HIP runtime call failed; see lg_last_error()                       */
 #define LG_ERR_STATE 3     /* call order violated (e.g. forward before weights were finalised)     */
+/* per-pair codes of lg_forward_io.status (device array; the call itself returned LG_OK): */
+#define LG_ERR_RANGE 4     /* LG_FLAG_CHECK_FINITE: a value of this pair's residual stream or of its q / k / v left the f16 operand range
+                              (|x| >= 65504, inf or NaN: the input domain of LG_PREC_F16X3 / _F16 / _BF16); its scores are not to be trusted */
+#define LG_ERR_DEVICE 5    /* an internal device-side wait expired (adaptive compaction): results of this forward are invalid */
 
 /* Mirrors LightGlue.default_conf (lightglue.py:322-335) for the keys the forward path reads. */
 typedef struct lg_config {
@@ -60,6 +64,10 @@ typedef struct lg_engine lg_engine;
  * match list replacing the per-pair torch.where loop (lightglue.py:593-602). */
 #define LG_FLAG_NO_PRUNING 1u /* skip point pruning for this call: the reference's padded/compiled
                                  path does the same (lightglue.py:529 `and not do_compile`)        */
+#define LG_FLAG_EXT 2u        /* the caller's struct carries the round-5 extension fields (everything after `log_assignment`); without
+                                 the flag the engine never reads them (callers built against the round-4 header keep working)          */
+#define LG_FLAG_CHECK_FINITE 4u /* range guard (needs LG_FLAG_EXT and `status`): every fused tail and q/k/v projection also tests the
+                                 values it is about to split into f16 planes — one compare per value — and flags the pair           */
 
 typedef struct lg_forward_io {
     int32_t batch, n0, n1;
@@ -86,6 +94,21 @@ typedef struct lg_forward_io {
      * padding of a ragged batch) hold -inf; the corner is 0 as in the reference.  NULL = not produced
      * (the match outputs never need the matrix materialised). */
     float *log_assignment;
+    /* ---- round-5 extension: read only when flags & LG_FLAG_EXT; every pointer optional (NULL = not produced) ----
+     * The reference's output dict holds int64 indices and, without pruning, float `prune0/1` (lightglue.py:616-629); the fields
+     * below let the engine write those dtypes itself (one kernel at the end of the forward) instead of the caller widening /
+     * filling them with framework kernels.  The int32 outputs above stay required: they are what the engine computes in. */
+    int64_t *matches0_i64, *matches1_i64;  /* [B][n0], [B][n1]                                                        */
+    int64_t *matches_i64;                  /* [B][min(n0,n1)][2] (rows >= n_matches[b] are not written)               */
+    int64_t *stop_i64;                     /* [B]                                                                     */
+    int64_t *prune0_i64, *prune1_i64;      /* pruning enabled: the final layer counters (lightglue.py:555-558, :605-614) */
+    float *prune0_f32, *prune1_f32;        /* pruning disabled: n_layers for live rows (lightglue.py:616-617), 0 for the
+                                              padding rows of a ragged batch                                          */
+    /* One packed int32 row per pair, the wire format of the pair-sharded multi-GPU path (lightglue_amd/parallel.py, DESIGN.md
+     * section 6): [matches0 (n0) | scores0 bit patterns (n0) | matches1 (n1) | scores1 bit patterns (n1) | stop], row stride
+     * wire_stride >= 2 n0 + 2 n1 + 1 elements.  lg_unpack_wire() is the inverse on the receiving side. */
+    int32_t *wire; int64_t wire_stride;
+    int32_t *status;                       /* [B] LG_OK / LG_ERR_RANGE / LG_ERR_DEVICE per pair                       */
 } lg_forward_io;
 
 /* Last error message of the calling thread (never NULL). */
@@ -111,6 +134,12 @@ int lg_engine_reserve(lg_engine* e, int32_t max_batch, int32_t max_n0, int32_t m
 /* Enqueue one forward (lightglue.py:483-629) on `hip_stream` (a hipStream_t, NULL = default stream).
  * Asynchronous: no host synchronisation when the workspace is already large enough. */
 int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream);
+
+/* Inverse of lg_forward_io.wire on gathered rows (stateless; device pointers; replaces the slice / widen / index_select chain of
+ * an all-gather consumer): row r of `wire` (stride wire_stride) goes to output pair order[r] (NULL = r; negative = skip the row); int64 indices and stop,
+ * fp32 scores — the dtypes of the reference's output dict. */
+int lg_unpack_wire(const int32_t* wire, int64_t wire_stride, int32_t pairs, int32_t n0, int32_t n1, const int32_t* order,
+                   int64_t* matches0, float* scores0, int64_t* matches1, float* scores1, int64_t* stop, void* hip_stream);
 
 /* Engine options (defaults are the product configuration; the others exist for tests, A/B measurements and profiling):
  *   "fused_tail"   1  out_proj + ffn + LayerNorm + GELU + residual as one kernel (lg_tail.hip); 0 = per-op GEMM kernels

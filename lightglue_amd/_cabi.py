@@ -15,13 +15,13 @@ from pathlib import Path
 _LIB_PATH = Path(os.environ.get("LIGHTGLUE_AMD_LIB") or Path(__file__).resolve().parent / "liblightglue_amd.so")
 
 LG_PREC = {"fp32": 0, "bf16": 1, "fp16": 2, "f16x3": 4}   # include/lightglue_amd.h LG_PREC_* (3 was split-bf16, removed in round 3)
-LG_OK, LG_ERR_INVALID, LG_ERR_HIP, LG_ERR_STATE = 0, 1, 2, 3
-LG_FLAG_NO_PRUNING = 1
+LG_OK, LG_ERR_INVALID, LG_ERR_HIP, LG_ERR_STATE, LG_ERR_RANGE, LG_ERR_DEVICE = 0, 1, 2, 3, 4, 5
+LG_FLAG_NO_PRUNING, LG_FLAG_EXT, LG_FLAG_CHECK_FINITE = 1, 2, 4
 
 # every symbol include/lightglue_amd.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (
     "lg_last_error", "lg_version", "lg_engine_create", "lg_engine_destroy", "lg_engine_set_weight",
-    "lg_engine_finalize_weights", "lg_engine_reserve", "lg_engine_forward", "lg_engine_set_option",
+    "lg_engine_finalize_weights", "lg_engine_reserve", "lg_engine_forward", "lg_unpack_wire", "lg_engine_set_option",
     "lg_engine_debug_stop_after", "lg_engine_debug_read", "lg_engine_debug_caps",
     "lg_profile_num_classes", "lg_profile_class_name", "lg_engine_profile_enable", "lg_engine_profile_read",
     "lg_sp_sample_descriptors", "lg_sp_detect_workspace_bytes", "lg_sp_detect",
@@ -49,6 +49,10 @@ class LgForwardIO(C.Structure):
         ("matches0", _fp), ("matches1", _fp), ("scores0", _fp), ("scores1", _fp), ("stop", _fp),
         ("prune0", _fp), ("prune1", _fp), ("matches", _fp), ("match_scores", _fp), ("n_matches", _fp),
         ("num0", _fp), ("num1", _fp), ("log_assignment", _fp),
+        # round-5 extension (read by the engine only when flags & LG_FLAG_EXT)
+        ("matches0_i64", _fp), ("matches1_i64", _fp), ("matches_i64", _fp), ("stop_i64", _fp),
+        ("prune0_i64", _fp), ("prune1_i64", _fp), ("prune0_f32", _fp), ("prune1_f32", _fp),
+        ("wire", _fp), ("wire_stride", C.c_int64), ("status", _fp),
     ]
 
 
@@ -82,6 +86,7 @@ def load() -> C.CDLL:
     lib.lg_engine_finalize_weights.argtypes = [C.c_void_p]
     lib.lg_engine_reserve.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.lg_engine_forward.argtypes = [C.c_void_p, C.POINTER(LgForwardIO), C.c_void_p]
+    lib.lg_unpack_wire.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7
     lib.lg_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
     lib.lg_engine_debug_stop_after.argtypes = [C.c_void_p, C.c_int32]
     lib.lg_engine_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]

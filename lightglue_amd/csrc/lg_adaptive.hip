@@ -20,6 +20,7 @@ __global__ __launch_bounds__(DNT) void adapt_decide_kernel(AdaptArgs a) {
     __shared__ int sh_cnt[DNW];
     __shared__ int sh_stop;
     __shared__ int sh_newlen[2];
+    if (pair == 0 && tid == 0 && a.compact_ticket) *a.compact_ticket = 0;   // the compaction launched behind this kernel deals its work items from 0
     if (!a.active[pair]) {
         // a pair that stopped (or lost all points of an image) at an earlier layer: make sure adapt_compact skips it —
         // len_old of the layer that pruned it must not be replayed at every later layer
@@ -96,9 +97,11 @@ __global__ __launch_bounds__(DNT) void adapt_decide_kernel(AdaptArgs a) {
 // In place is still safe because dst <= src: a chunk only writes rows of ITSELF or of LOWER chunks of its segment, and it does so after those
 // chunks have published "all my rows are in registers" (one relaxed agent-scope flag per chunk, value = this launch's epoch; no payload travels
 // through memory between workgroups, so no release / acquire of data is involved — the flag only orders the consumer's stores behind the producer's
-// completed loads).  Deadlock freedom does not lean on dispatch order: the grid never exceeds one workgroup per CU (<= 256, each far below a CU's
-// register / LDS budget, so all are co-resident), a workgroup takes its items in ascending id, item id = chunk * segments + seg, and an item waits
-// only for items with lower ids; the spin is bounded anyway (an expired wait raises a.compact_err instead of hanging the GPU).
+// completed loads).  Deadlock freedom (round 5): work items are dealt by an atomic TICKET, not by workgroup id.  Item id = chunk * segments +
+// seg, an item waits only for items with LOWER ids, and a lower ticket is always held by a workgroup that is already running (it drew the ticket) —
+// so the lowest unfinished item never waits and every wait ends, whatever the grid size, the number of co-resident workgroups (CU masks, partitioned
+// modes, a second process on the GPU) or the dispatch order.  The spin is bounded anyway; a wait that expires SKIPS the chunk's stores (rows stay where
+// they were instead of overwriting unread ones) and raises a.compact_err, which the forward reports as LG_ERR_DEVICE in io->status.
 // Memory ops are raw BUFFER loads / stores: a lane that has nothing to move gets an offset past the end of the buffer, for which the hardware
 // returns zeros / drops the store WITHOUT touching memory — 40 independent 16-byte loads per thread with no branch between them (a branch
 // around a load makes hipcc wait for it at the join, i.e. one exposed round trip per piece).
@@ -113,7 +116,16 @@ __global__ __launch_bounds__(256) void adapt_compact_kernel(AdaptArgs a) {
     __shared__ int sh_d[CROWS];                // destination row of each row of the chunk, -1 = nothing to move (dropped, or already in place)
     const long long Rrows = (long long)a.rs.B * (a.rs.cap0 + a.rs.cap1);
     const __amdgpu_buffer_rsrc_t rx = compact_rsrc(a.X, Rrows * 1024), rt = compact_rsrc(w < 2 ? a.cosb : a.sinb, Rrows * 128);   // waves 0, 1 move cos rows, waves 2, 3 sin rows
-    for (int item = blockIdx.x; item < nseg * nchunk; item += gridDim.x) {
+    __shared__ int sh_item;
+    int ticket = tid == 0 ? atomicAdd(a.compact_ticket, 1) : 0;
+    for (;;) {
+        __syncthreads();                         // everybody has read the previous ticket (and the previous item's readers of sh_d are done)
+        if (tid == 0) sh_item = ticket;
+        __syncthreads();
+        const int item = sh_item;
+        if (item >= nseg * nchunk) break;
+        if (tid == 0) ticket = atomicAdd(a.compact_ticket, 1);   // the next ticket travels while this item is processed (a workgroup's tickets ascend, so the
+                                                                 // lowest unfinished item is still always some running workgroup's current or next one)
         const int chunk = item / nseg, seg = item - chunk * nseg;
         const int Lold = a.len_old[seg];
         if (Lold < 0) continue;                  // pruning not applied to this segment at this layer
@@ -129,8 +141,7 @@ __global__ __launch_bounds__(256) void adapt_compact_kernel(AdaptArgs a) {
             if (myd >= 0) prune[myv] += 1;
             continue;
         }
-        __syncthreads();                         // the previous item's readers of sh_d are done
-        if (tid < CROWS) sh_d[tid] = (myd >= 0 && myd != r0 + tid) ? myd : -1;
+        if (tid < CROWS) sh_d[tid] = (myd >= 0 && myd != r0 + tid) ? myd : -1;   // (the loop head's barrier: the previous item's readers are done)
         __syncthreads();
         // descriptor rows: wave w, step u -> row 4u + w of the chunk, one 16-byte piece per lane (a whole 1 KB row per wave instruction)
         u32x4 vx[32], vt[8]; int dx[32], dt[8];
@@ -154,14 +165,18 @@ __global__ __launch_bounds__(256) void adapt_compact_kernel(AdaptArgs a) {
         __syncthreads();
         int* flags = a.compact_flags + (long long)seg * nchunk;
         if (tid == 0) __hip_atomic_store(flags + chunk, a.compact_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __shared__ int sh_expired;
+        if (tid == 0) sh_expired = 0;
+        __syncthreads();
         if (tid < chunk) {                       // lower chunks of this segment: their rows are the only foreign ones this chunk overwrites
             int spins = 0;
             while (__hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.compact_epoch) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1 << 20)) { *a.compact_err = 1; break; }
+                if (++spins > (1 << 20)) { *a.compact_err = 1; sh_expired = 1; break; }
             }
         }
         __syncthreads();
+        if (sh_expired) continue;                // never expected (see above): leave this chunk's rows where they are rather than overwrite unread ones
         const unsigned xdst0 = (unsigned)base * 1024u + (unsigned)lane * 16u, tdst0 = (unsigned)base * 128u + (unsigned)(tt & 7) * 16u;
 #pragma unroll
         for (int u = 0; u < 32; ++u) __builtin_amdgcn_raw_buffer_store_b128(vx[u], rx, dx[u] >= 0 ? xdst0 + (unsigned)dx[u] * 1024u : CSKIP, 0, 0);
@@ -174,7 +189,7 @@ __global__ __launch_bounds__(256) void adapt_compact_kernel(AdaptArgs a) {
 hipError_t launch_adapt(const AdaptArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(adapt_decide_kernel, dim3(a.rs.B), dim3(DNT), 0, s, a);
     if (a.do_prune) {
-        const int items = 2 * a.rs.B * a.compact_chunks;
+        const int items = 2 * a.rs.B * a.compact_chunks;   // dealt by ticket: the grid size is a throughput choice only (one workgroup per CU of an MI355X)
         hipLaunchKernelGGL(adapt_compact_kernel, dim3(items < 256 ? items : 256), dim3(256), 0, s, a);
     }
     return hipGetLastError();

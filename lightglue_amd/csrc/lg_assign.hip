@@ -297,6 +297,11 @@ __global__ __launch_bounds__(256) void log_assignment_kernel(AssignArgs a) {
     const int len0 = a.rs.len[2 * pair], len1 = a.rs.len[2 * pair + 1];
     const int base0 = seg_row_base(a.rs, 2 * pair), base1 = seg_row_base(a.rs, 2 * pair + 1);
     float* out = a.log_assignment + (long long)pair * (a.n0 + 1) * (a.n1 + 1);
+    if (len0 == 0 || len1 == 0) {   // a pair that never ran a layer, or lost every point of an image (ref :539-540: the reference returns before it builds any
+        // score): its matchability terms were never written — leave the -inf fill, define the corner
+        if (r == a.rs.cap0 && tid == 0) out[(long long)a.n0 * (a.n1 + 1) + a.n1] = 0.f;
+        return;
+    }
     if (r == a.rs.cap0) {   // dustbin row: logsigmoid(-z1) (ref :276), corner 0 (ref :269 zero-initialised)
         for (int c = tid; c < len1; c += 256) out[(long long)a.n0 * (a.n1 + 1) + a.ind[base1 + c]] = a.lsneg[base1 + c];
         if (tid == 0) out[(long long)a.n0 * (a.n1 + 1) + a.n1] = 0.f;

@@ -121,6 +121,7 @@ struct lg_engine {
     int* CBI;
     void *Q, *K, *VT;
     int *IND, *DST, *LEN, *LEN_ORIG, *LEN_OLD, *ACTIVE, *FINAL_LAYER, *ARG0, *ARG1;
+    int* RANGEF = nullptr;   // [B] range-guard flags (LG_FLAG_CHECK_FINITE), zeroed by init_state_kernel
     int debug_stop = -1;
     // ---- per-kernel-class HIP-event timing (bench.py roofline leg)
     bool profiling = false, prof_open = false;
@@ -209,8 +210,10 @@ const HostTensor* find(const lg_engine* e, const std::string& name, std::initial
 }
 
 __global__ void init_state_kernel(int B, int n0, int n1, int L, const int* num0, const int* num1, int* len, int* len_orig, int* len_old,
-                                  int* active, int* final_layer, int* prune0, int* prune1) {
+                                  int* active, int* final_layer, int* prune0, int* prune1, int* range_flag = nullptr, int* device_err = nullptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (range_flag && i < B) range_flag[i] = 0;
+    if (device_err && i == 0) *device_err = 0;
     auto count = [](const int* num, int pair, int n) { int v = num ? num[pair] : n; return v < 0 ? 0 : (v > n ? n : v); };
     if (len && i < B) {
         const int l0 = count(num0, i, n0), l1 = count(num1, i, n1);
@@ -224,9 +227,63 @@ __global__ void init_state_kernel(int B, int n0, int n1, int L, const int* num0,
     if (prune0) for (long long k = i; k < (long long)B * n0; k += (long long)gridDim.x * blockDim.x) prune0[k] = (int)(k % n0) < count(num0, (int)(k / n0), n0);
     if (prune1) for (long long k = i; k < (long long)B * n1; k += (long long)gridDim.x * blockDim.x) prune1[k] = (int)(k % n1) < count(num1, (int)(k / n1), n1);
 }
-__global__ void write_stop_kernel(int B, const int* final_layer, int* stop) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) stop[i] = final_layer[i] + 1;
+// ---- the last kernel of every forward: `stop` (ref :604 / :575), and — round-5 extension of lg_forward_io — the outputs in the reference's own dtypes
+// (int64 indices ref :619-629, float prune0/1 without pruning ref :616-617), the packed wire row of the pair-sharded path, and the per-pair status.
+// Replaces the framework kernels the Python shim ran behind the forward (one `.long()` over the int32 block, `torch.full`, the ragged masks) and the
+// five slice copies of parallel.py's pack.  grid (ceil(span / 256), B), span = max(n0, n1, 2 * min(n0, n1)).
+struct OutArgs {
+    int B, n0, n1, L, kmax;
+    const int* final_layer; int stop_const;   // final_layer == nullptr: every pair's stop is stop_const (an empty image: 1)
+    int* stop;
+    const int* m0; const int* m1; const float* s0; const float* s1; const int* matches; const int* n_matches;
+    const int* prune0; const int* prune1; const int* num0; const int* num1;
+    long long* m0_64; long long* m1_64; long long* matches_64; long long* stop_64; long long* prune0_64; long long* prune1_64;
+    float* prune0_f; float* prune1_f;
+    int* wire; long long wire_stride;
+    int* status; const int* range_flag; const int* device_err;
+};
+__global__ __launch_bounds__(256) void write_outputs_kernel(OutArgs a) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int stop = a.final_layer ? a.final_layer[b] + 1 : a.stop_const;
+    int* wrow = a.wire ? a.wire + (long long)b * a.wire_stride : nullptr;
+    auto count = [](const int* num, int pair, int n) { int v = num ? num[pair] : n; return v < 0 ? 0 : (v > n ? n : v); };
+    if (i == 0) {
+        a.stop[b] = stop;
+        if (a.stop_64) a.stop_64[b] = stop;
+        if (wrow) wrow[2 * a.n0 + 2 * a.n1] = stop;
+        if (a.status) a.status[b] = (a.device_err && *a.device_err) ? LG_ERR_DEVICE : ((a.range_flag && a.range_flag[b]) ? LG_ERR_RANGE : LG_OK);
+    }
+    if (i < a.n0) {
+        const long long k = (long long)b * a.n0 + i;
+        const int m = a.m0[k];
+        if (a.m0_64) a.m0_64[k] = m;
+        if (a.prune0_64) a.prune0_64[k] = a.prune0[k];
+        if (a.prune0_f) a.prune0_f[k] = i < count(a.num0, b, a.n0) ? (float)a.L : 0.f;
+        if (wrow) { wrow[i] = m; wrow[a.n0 + i] = __float_as_int(a.s0[k]); }
+    }
+    if (i < a.n1) {
+        const long long k = (long long)b * a.n1 + i;
+        const int m = a.m1[k];
+        if (a.m1_64) a.m1_64[k] = m;
+        if (a.prune1_64) a.prune1_64[k] = a.prune1[k];
+        if (a.prune1_f) a.prune1_f[k] = i < count(a.num1, b, a.n1) ? (float)a.L : 0.f;
+        if (wrow) { wrow[2 * a.n0 + i] = m; wrow[2 * a.n0 + a.n1 + i] = __float_as_int(a.s1[k]); }
+    }
+    if (a.matches_64 && i < 2 * a.kmax && (i >> 1) < a.n_matches[b]) {
+        const long long k = (long long)b * a.kmax * 2 + i;
+        a.matches_64[k] = a.matches[k];
+    }
+}
+// inverse of the wire row on gathered rows (lg_unpack_wire).  grid (ceil(max(n0, n1, 1) / 256), pairs)
+__global__ __launch_bounds__(256) void unpack_wire_kernel(const int* wire, long long stride, int n0, int n1, const int* order,
+                                                           long long* m0, float* s0, long long* m1, float* s1, long long* stop) {
+    const int r = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int* row = wire + (long long)r * stride;
+    const long long d = order ? order[r] : r;
+    if (d < 0) return;                         // a padding row of a short shard
+    if (i < n0) { if (m0) m0[d * n0 + i] = row[i]; if (s0) s0[d * n0 + i] = __int_as_float(row[n0 + i]); }
+    if (i < n1) { if (m1) m1[d * n1 + i] = row[2 * n0 + i]; if (s1) s1[d * n1 + i] = __int_as_float(row[2 * n0 + n1 + i]); }
+    if (i == 0 && stop) stop[d] = row[2 * n0 + 2 * n1];
 }
 
 int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
@@ -253,7 +310,7 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
         add(R * (size_t)e->cfg.input_dim * 4);                  // XIN
         for (int i = 0; i < 3; ++i) add(R * 256 * as);          // Q K VT
         add(R * 4); add(R * 4);                                 // IND DST
-        for (int i = 0; i < 5; ++i) add((size_t)nB * 2 * 4);    // LEN LEN_ORIG LEN_OLD ACTIVE FINAL_LAYER
+        for (int i = 0; i < 6; ++i) add((size_t)nB * 2 * 4);    // LEN LEN_ORIG LEN_OLD ACTIVE FINAL_LAYER RANGEF
         add(R / 128 * 8 + 256);                                 // CFLAGS: 2B * max(cap0, cap1) / 128 ints <= 2 R / 128, + the error word
         add(R * 16); add(R * 16);                               // TAILDBG TAILDBG2 (16 bytes per row: [R / 64 workgroups][8 waves][8 stamps], or [R / 128][16 half-waves ...] of the split attention's taps)
         total += 4096;
@@ -284,6 +341,7 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
     e->IND = (int*)take("IND", R * 4); e->DST = (int*)take("DST", R * 4);
     e->LEN = (int*)take("LEN", (size_t)B * 2 * 4); e->LEN_ORIG = (int*)take("LEN_ORIG", (size_t)B * 2 * 4); e->LEN_OLD = (int*)take("LEN_OLD", (size_t)B * 2 * 4);
     e->ACTIVE = (int*)take("ACTIVE", (size_t)B * 4); e->FINAL_LAYER = (int*)take("FINAL_LAYER", (size_t)B * 4);
+    e->RANGEF = (int*)take("RANGEF", (size_t)B * 4);
     e->CFLAGS = (int*)take("CFLAGS", (size_t)2 * B * ((c0 > c1 ? c0 : c1) / 128) * 4 + 256); e->cflags_clean = false;
     e->TAILDBG = (long long*)take("TAILDBG", R * 16); e->TAILDBG2 = (long long*)take("TAILDBG2", R * 16);
     if (ar.used > e->ws_bytes) return fail(LG_ERR_STATE, "workspace carve overflow");
@@ -342,7 +400,7 @@ int lg_engine_profile_read(lg_engine* e, double* ms, int64_t* count, int32_t n) 
 }
 
 const char* lg_last_error(void) { return g_err.c_str(); }
-const char* lg_version(void) { return "lightglue_amd 0.2 (gfx950)"; }
+const char* lg_version(void) { return "lightglue_amd 0.3 (gfx950)"; }
 
 int lg_engine_create(const lg_config* cfg, lg_engine** out) {
     if (!cfg || !out) return fail(LG_ERR_INVALID, "null argument");
@@ -719,6 +777,26 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
     if (e->cfg.add_scale_ori && (!io->scales0 || !io->oris0 || !io->scales1 || !io->oris1)) return fail(LG_ERR_INVALID, "scales/oris required");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const int max_matches = n0 < n1 ? n0 : n1;
+    const bool ext = (io->flags & LG_FLAG_EXT) != 0;            // round-5 extension fields present
+    const bool check_finite = ext && (io->flags & LG_FLAG_CHECK_FINITE) != 0;
+    if ((io->flags & LG_FLAG_CHECK_FINITE) && (!ext || !io->status)) return fail(LG_ERR_INVALID, "LG_FLAG_CHECK_FINITE needs LG_FLAG_EXT and a status array");
+    if (ext && io->wire && io->wire_stride < 2LL * n0 + 2LL * n1 + 1) return fail(LG_ERR_INVALID, "wire_stride < 2 n0 + 2 n1 + 1");
+    if (ext && do_prune && ((io->prune0_f32 || io->prune1_f32))) return fail(LG_ERR_INVALID, "prune0_f32 / prune1_f32 are the outputs of a forward WITHOUT pruning");
+    if (ext && !do_prune && ((io->prune0_i64 || io->prune1_i64))) return fail(LG_ERR_INVALID, "prune0_i64 / prune1_i64 are the outputs of a forward WITH pruning");
+    auto write_outputs = [&](const int* final_layer, int stop_const, const int* range_flag, const int* device_err) -> hipError_t {
+        OutArgs o{};
+        o.B = B; o.n0 = n0; o.n1 = n1; o.L = L; o.kmax = max_matches; o.final_layer = final_layer; o.stop_const = stop_const; o.stop = io->stop;
+        o.m0 = io->matches0; o.m1 = io->matches1; o.s0 = io->scores0; o.s1 = io->scores1; o.matches = io->matches; o.n_matches = io->n_matches;
+        o.prune0 = io->prune0; o.prune1 = io->prune1; o.num0 = io->num0; o.num1 = io->num1;
+        if (ext) {
+            o.m0_64 = (long long*)io->matches0_i64; o.m1_64 = (long long*)io->matches1_i64; o.matches_64 = (long long*)io->matches_i64; o.stop_64 = (long long*)io->stop_i64;
+            o.prune0_64 = (long long*)io->prune0_i64; o.prune1_64 = (long long*)io->prune1_i64; o.prune0_f = io->prune0_f32; o.prune1_f = io->prune1_f32;
+            o.wire = io->wire; o.wire_stride = io->wire_stride; o.status = io->status; o.range_flag = range_flag; o.device_err = device_err;
+        }
+        int span = n0 > n1 ? n0 : n1; if (2 * max_matches > span) span = 2 * max_matches; if (span < 1) span = 1;
+        hipLaunchKernelGGL(write_outputs_kernel, dim3((span + 255) / 256, B), dim3(256), 0, s, o);
+        return hipGetLastError();
+    };
 
     if (n0 == 0 || n1 == 0) {  // ref :539-540, :568-588: well-formed empty result, stop = 1
         if (n0) { HIPCHK(hipMemsetAsync(io->matches0, 0xFF, sizeof(int) * (size_t)B * n0, s)); HIPCHK(hipMemsetAsync(io->scores0, 0, 4 * (size_t)B * n0, s)); }
@@ -726,10 +804,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
         HIPCHK(hipMemsetAsync(io->n_matches, 0, sizeof(int) * (size_t)B, s));
         hipLaunchKernelGGL(init_state_kernel, dim3(64), dim3(256), 0, s, B, n0, n1, L, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                            (do_prune && n0) ? io->prune0 : nullptr, (do_prune && n1) ? io->prune1 : nullptr);
-        // stop = 1 for every pair
-        std::vector<int> ones(B, 1);
-        HIPCHK(hipMemcpyAsync(io->stop, ones.data(), sizeof(int) * (size_t)B, hipMemcpyHostToDevice, s));
-        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(write_outputs(nullptr, 1, nullptr, nullptr));   // stop = 1 for every pair (+ the extension outputs of an empty result)
         return LG_OK;
     }
 
@@ -743,8 +818,10 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
     int step = 0;
 #define STEP_DONE() do { if (e->debug_stop >= 0 && step >= e->debug_stop) return LG_OK; ++step; } while (0)
 
+    int* const device_err = e->CFLAGS + (size_t)2 * B * ((c0 > c1 ? c0 : c1) / 128);   // error word + compaction ticket behind the chunk flags (lg_adaptive.hip)
     hipLaunchKernelGGL(init_state_kernel, dim3(64), dim3(256), 0, s, B, n0, n1, L, io->num0, io->num1, e->LEN, e->LEN_ORIG, e->LEN_OLD, e->ACTIVE, e->FINAL_LAYER,
-                       do_prune ? io->prune0 : nullptr, do_prune ? io->prune1 : nullptr);
+                       do_prune ? io->prune0 : nullptr, do_prune ? io->prune1 : nullptr, e->RANGEF, device_err);
+    int* const range_flag = check_finite ? e->RANGEF : nullptr;
     // prep (+ descriptor copy) as its own launch, or — input_dim == 256, no debug stop — inside the first projection launch (lg_proj.hip proj_first_kernel)
     const bool fuse_prep = e->fused_prep && e->cfg.input_dim == D && e->debug_stop < 0 && e->tail_timing != 2;
     PrepArgs p{};
@@ -777,7 +854,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
         pj.bias = blk == 0 ? e->b_sqkv + (size_t)layer * 768 : e->b_cqkv + (size_t)layer * 512;
         pj.Nout = blk == 0 ? 768 : 512; pj.n_qk_groups = blk == 0 ? 2 : 1;
         pj.cosb = blk == 0 ? e->COS : nullptr; pj.sinb = blk == 0 ? e->SIN : nullptr;
-        pj.dbg = nullptr;
+        pj.dbg = nullptr; pj.range_flag = range_flag;
         return pj;
     };
     // fused_next: a tail kernel also runs the NEXT block's projection on the x tile it has just produced.  Across a
@@ -817,7 +894,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
             STEP_DONE();
             if (e->fused_tail) {   // out_proj + ffn.0 + LayerNorm + GELU + ffn.3 + residual in one kernel (lg_tail.hip)
                 TailArgs ta{};
-                ta.rs = rs_act; ta.X = e->X; ta.CTX = e->CTX;
+                ta.rs = rs_act; ta.X = e->X; ta.CTX = e->CTX; ta.range_flag = range_flag;
                 ta.Wcat = (blk ? e->w_ctail_cat : e->w_stail_cat) + (size_t)i * e->tail_cat_layer_bytes;
                 ta.bcat = (blk ? e->b_ccat : e->b_scat) + (size_t)i * 512;
                 ta.gamma = (blk ? e->ln_c_g : e->ln_s_g) + (size_t)i * 512; ta.beta = (blk ? e->ln_c_b : e->ln_s_b) + (size_t)i * 512;
@@ -919,7 +996,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
             ad.width_conf = (float)(1.0 - e->cfg.width_confidence);
             ad.pruning_min_kpts = e->cfg.pruning_min_kpts;
             ad.do_stop = do_stop; ad.do_prune = prune_now;
-            ad.compact_chunks = (c0 > c1 ? c0 : c1) / 128; ad.compact_flags = e->CFLAGS; ad.compact_err = e->CFLAGS + (size_t)2 * B * ad.compact_chunks;
+            ad.compact_chunks = (c0 > c1 ? c0 : c1) / 128; ad.compact_flags = e->CFLAGS; ad.compact_err = device_err; ad.compact_ticket = device_err + 1;
             if (prune_now && !e->cflags_clean) {   // fresh carve: whatever the arena held there must not look like an epoch
                 HIPCHK(hipMemsetAsync(e->CFLAGS, 0, (size_t)2 * B * ad.compact_chunks * 4 + 256, s));
                 e->cflags_clean = true;
@@ -961,11 +1038,21 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
         TRY(prof_begin(e, PC_ASSIGN, s));
         HIPCHK(launch_assign(as, s));
         TRY(prof_end(e, s));
-        hipLaunchKernelGGL(write_stop_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, e->FINAL_LAYER, io->stop);
-        HIPCHK(hipGetLastError());
+        HIPCHK(write_outputs(e->FINAL_LAYER, 0, range_flag, device_err));
     }
 #undef STEP_DONE
 #undef TRY
+    return LG_OK;
+}
+
+int lg_unpack_wire(const int32_t* wire, int64_t wire_stride, int32_t pairs, int32_t n0, int32_t n1, const int32_t* order,
+                   int64_t* matches0, float* scores0, int64_t* matches1, float* scores1, int64_t* stop, void* hip_stream) {
+    if (!wire || pairs < 0 || n0 < 0 || n1 < 0 || wire_stride < 2LL * n0 + 2LL * n1 + 1) return fail(LG_ERR_INVALID, "lg_unpack_wire: bad argument");
+    if (pairs == 0) return LG_OK;
+    int span = n0 > n1 ? n0 : n1; if (span < 1) span = 1;
+    hipLaunchKernelGGL(unpack_wire_kernel, dim3((span + 255) / 256, pairs), dim3(256), 0, static_cast<hipStream_t>(hip_stream), wire, (long long)wire_stride, n0, n1,
+                       order, (long long*)matches0, scores0, (long long*)matches1, scores1, (long long*)stop);
+    HIPCHK(hipGetLastError());
     return LG_OK;
 }
 

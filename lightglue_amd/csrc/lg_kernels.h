@@ -48,6 +48,7 @@ struct ProjArgs {
     const float* cosb; const float* sinb;            // rotary tables [R][32] or nullptr
     int n_qk_groups; int R;
     long long* dbg;                                  // profiling tap: [blocks][8 waves][8] shader-clock stamps, or nullptr
+    int* range_flag;                                 // [B] or nullptr: LG_FLAG_CHECK_FINITE — set to 1 when a q / k / v value of a live row is not |v| < 65504
 };
 hipError_t launch_proj(int prec, int attn_prec, const ProjArgs& a, hipStream_t s);
 
@@ -76,6 +77,7 @@ struct TailArgs {
     const float* gamma; const float* beta;   // LayerNorm(512)
     const void* W2; const float* b2;         // [256][512] fragment-packed, [256]
     long long* dbg;                          // profiling tap: [blocks][8 waves][8] shader-clock stamps, or nullptr
+    int* range_flag;                         // [B] or nullptr: LG_FLAG_CHECK_FINITE — set to 1 when a new x value of a live row is not |x| < 65504 (inf / NaN included)
     int row_tiles;                           // 16-row tiles per workgroup: 4 (default; 0 = 4), 2 or 1 for under-filled grids (16-bit modes)
     // optional 256 -> 1 heads on the NEW x rows, sigmoid applied (token confidence ref :89-94, matchability ref :298-299): up to two
     // weight vectors [256] + bias [1] -> out [R]; nullptr = off.  Replaces a rowdot launch (and its re-read of X) per layer in the
@@ -160,7 +162,8 @@ struct AdaptArgs {
     int compact_chunks;     // 128-row chunks per segment = max(cap0, cap1) / 128
     int* compact_flags;     // [2B][compact_chunks] "chunk is in registers" flags, value = compact_epoch of the launch that set them
     int compact_epoch;      // > 0, different for every launch (never reset: stale flags of earlier launches compare unequal)
-    int* compact_err;       // set to 1 if a bounded flag wait expired (never expected; read back by the engine's debug interface)
+    int* compact_err;       // set to 1 if a bounded flag wait expired (never expected): the chunk's stores are SKIPPED and the forward reports LG_ERR_DEVICE in io->status
+    int* compact_ticket;    // work-item counter of adapt_compact_kernel (reset by adapt_decide_kernel of the same launch_adapt)
 };
 hipError_t launch_adapt(const AdaptArgs& a, hipStream_t s);
 

@@ -185,6 +185,11 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
     // not alias the tables, so a load placed after a store stays there (one exposed round trip per iteration)
     if constexpr (!AHEAD) load_operands();
     typedef TA ta4 __attribute__((ext_vector_type(4)));
+    // range guard (LG_FLAG_CHECK_FINITE; workgroup-uniform switch): q / k / v values of live rows, tested right in front of their f16 split
+    const bool range_on = a.range_flag != nullptr;
+    const int live_rows = range_on ? a.rs.len[t.seg] - t.r0 : 0;
+    bool out_of_range = false;
+    auto bad4 = [](const f32x4& v) { return !(fabsf(v[0]) < 65504.f) | !(fabsf(v[1]) < 65504.f) | !(fabsf(v[2]) < 65504.f) | !(fabsf(v[3]) < 65504.f); };
     constexpr int OPART = PJ<PREC>::OPART;
     static_assert(OPART == 1 || sizeof(TA) == 2, "split q / k / v planes are f16");
     if constexpr (HAS_PAIR) {                                  // q / k (or qk) pair: 8 consecutive channels per lane and keypoint row
@@ -203,6 +208,7 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
                 v1[2] = u1[2] * c[3] - u1[3] * sn[3]; v1[3] = u1[3] * c[3] + u1[2] * sn[3];
             }
             v0 *= QK_PRESCALE; v1 *= QK_PRESCALE;
+            if (range_on && pj_row<MT>(mt, lr) < live_rows) out_of_range |= bad4(v0) | bad4(v1);
             TA* dst = base + ((long long)head * R + row) * 64 + d0 + 8 * g;
             if constexpr (OPART == 2) {                        // hi plane + lo plane (f16 of the residual, exact subtraction in fp32)
                 u32x4 hi, lo;
@@ -227,6 +233,13 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
             for (int q = 0; q < MT / 2; ++q) {
                 const f32x4 v0 = acc[2 * q][j] + bv[j], v1 = acc[2 * q + 1][j] + bv[j];
                 TA* dst = vrow + 32 * q + 8 * g;
+                if (range_on) {   // rows 32 q + 8 g + 0..3 (v0) and + 4..7 (v1)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        out_of_range |= (32 * q + 8 * g + r < live_rows) & !(fabsf(v0[r]) < 65504.f);
+                        out_of_range |= (32 * q + 8 * g + 4 + r < live_rows) & !(fabsf(v1[r]) < 65504.f);
+                    }
+                }
                 if constexpr (OPART == 2) {
                     u32x4 hi, lo;
                     split8_f16<true>(v0, v1, hi, lo);
@@ -241,6 +254,10 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
         } else {
             const f32x4 v = acc[0][j] + bv[j];
             TA* dst = vrow + 4 * g;
+            if (range_on) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out_of_range |= (4 * g + r < live_rows) & !(fabsf(v[r]) < 65504.f);
+            }
             if constexpr (OPART == 2) {
                 uint32_t h01, l01, h23, l23;
                 split2_f16(v[0], v[1], h01, l01); split2_f16(v[2], v[3], h23, l23);
@@ -252,6 +269,7 @@ __device__ __forceinline__ void proj_pass(const ProjArgs& a, const TileLoc& t, c
             }
         }
     }
+    if (range_on && out_of_range) a.range_flag[t.pair] = 1;
     stamp(3 + 2 * PASS);
 }
 

@@ -473,6 +473,9 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
     float hp0[MT], hp1[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) { hp0[mt] = 0.f; hp1[mt] = 0.f; }
+    // range guard (LG_FLAG_CHECK_FINITE; workgroup-uniform switch): the new residual rows are what the next kernels split into f16 planes
+    const bool range_on = a.range_flag != nullptr;
+    bool out_of_range = false;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int col = w * 32 + nt * 16 + 4 * g;
@@ -481,7 +484,10 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
         for (int mt = 0; mt < MT; ++mt) {
             const int row = mt * 16 + lr;
             const f32x4 xn = xres[mt][nt] + (acc2[mt][nt] + b2);
-            if (t.r0 + row < qlen) *reinterpret_cast<f32x4*>(a.X + (long long)(t.grow0 + row) * 256 + col) = xn;
+            if (t.r0 + row < qlen) {
+                *reinterpret_cast<f32x4*>(a.X + (long long)(t.grow0 + row) * 256 + col) = xn;
+                if (range_on) out_of_range |= !(fabsf(xn[0]) < 65504.f) | !(fabsf(xn[1]) < 65504.f) | !(fabsf(xn[2]) < 65504.f) | !(fabsf(xn[3]) < 65504.f);
+            }
             if (heads) {
                 hp0[mt] += (xn[0] * hw0[nt][0] + xn[1] * hw0[nt][1]) + (xn[2] * hw0[nt][2] + xn[3] * hw0[nt][3]);
                 hp1[mt] += (xn[0] * hw1[nt][0] + xn[1] * hw1[nt][1]) + (xn[2] * hw1[nt][2] + xn[3] * hw1[nt][3]);
@@ -502,6 +508,7 @@ __global__ __launch_bounds__(TTHREADS) void tail_kernel(TailArgs a) {
             }
         }
     }
+    if (range_on && out_of_range) a.range_flag[t.pair] = 1;   // (same value from every lane that sees one: no atomic needed)
     if (heads) {   // reduce over the 4 lane groups (the other column quarters of this wave), then over the 8 waves through LDS, in a fixed order
         f32x2* red2 = reinterpret_cast<f32x2*>(red);
 #pragma unroll

@@ -168,6 +168,10 @@ class LightGlue(nn.Module):
         self.static_lengths = None
         # extension: also return the full [B, M+1, N+1] log-assignment incl. dustbins (ref :265-277)
         self.return_log_assignment = False
+        # extension: range guard (include/lightglue_amd.h LG_FLAG_CHECK_FINITE).  The split-f16 arithmetic needs |x| < 65504 for the residual stream
+        # and q / k / v (like the reference's own fp16 mode); with the guard on, a forward whose values leave that range raises instead of returning
+        # inf / NaN scores.  Off by default (one compare per value in the tail and projection epilogues).
+        self.check_finite = False
         self._engine = None  # (handle, device_index, config signature)
         self._weights_sig = None
         self._plist = None
@@ -318,11 +322,21 @@ class LightGlue(nn.Module):
             _cabi.check(_cabi.load().lg_engine_reserve(h, batch, n0, n1))
 
     # ------------------------------------------------------------------ forward
-    def forward_raw(self, data: dict) -> dict:
+    def forward_raw(self, data: dict, wire: Optional[torch.Tensor] = None) -> dict:
         """The forward without output widening, ragged lists or the host synchronisation: int32 `matches0/1` [B, M|N], fp32
-        `matching_scores0/1`, int32 `stop` [B] — views of the engine's own output buffers, valid on the current stream.  Used by
-        `PairShardedMatcher`, which puts exactly these on the wire (int32 is enough for N <= 4096; the API widens to int64)."""
-        return self.forward(data, _raw=True)
+        `matching_scores0/1`, int32 `stop` and `status` [B] — views of the engine's own output buffers, valid on the current stream.
+        `wire`: optional int32 [pairs >= B][>= 2M + 2N + 1] buffer; the engine's last kernel then also packs one row per pair,
+        [matches0 | score0 bits | matches1 | score1 bits | stop] — the send buffer of `PairShardedMatcher` (int32 is enough for
+        N <= 4096; `lg_unpack_wire` widens on the receiving side)."""
+        return self.forward(data, _raw=True if wire is None else wire)
+
+    @staticmethod
+    def _raise_on_status(status) -> None:
+        bad = [(i, int(c)) for i, c in enumerate(status) if int(c) != _cabi.LG_OK]
+        if bad:
+            what = {_cabi.LG_ERR_RANGE: "values outside the f16 operand range (|x| >= 65504, inf or NaN; LG_ERR_RANGE)",
+                    _cabi.LG_ERR_DEVICE: "an internal device-side wait expired (LG_ERR_DEVICE)"}
+            raise _cabi.LightGlueAmdError("; ".join(f"pair {i}: {what.get(c, c)}" for i, c in bad[:8]))
 
     def forward_deferred(self, data: dict) -> "DeferredMatches":
         """The forward enqueued WITHOUT its host synchronisation: `.result()` of the returned handle waits for this forward
@@ -393,26 +407,38 @@ class LightGlue(nn.Module):
         do_compile = bool(self.static_lengths) and max(m, n) <= max(self.static_lengths)
         do_point_pruning = conf.width_confidence > 0 and not do_compile
 
-        # ---- outputs: ONE int32 and ONE fp32 allocation, carved into the tensors of the C ABI (16-byte aligned pieces);
-        # the int32 block is widened to int64 by a single kernel after the forward (ref dtypes :619-629)
+        # ---- outputs: ONE int32, ONE int64 and ONE fp32 allocation, carved into the tensors of the C ABI (16-byte aligned pieces).  The engine's
+        # last kernel writes the reference's dtypes itself (int64 indices / stop / prune counters, float prune0/1 without pruning, ref :616-629;
+        # round-5 extension of lg_forward_io): no framework kernel runs between or behind the engine's launches.
         kmax = min(m, n)
         r4 = lambda x: (x + 3) & ~3
-        isz = [b * m, b * n, b * kmax * 2, b * m if do_point_pruning else 0, b * n if do_point_pruning else 0, 2 * b]
-        ioff = [0]
-        for x in isz:
-            ioff.append(ioff[-1] + r4(x))
+        carve = lambda sizes: [sum(r4(x) for x in sizes[:k]) for k in range(len(sizes) + 1)]
+        isz = [b * m, b * n, b * kmax * 2, b * m if do_point_pruning else 0, b * n if do_point_pruning else 0, 3 * b]
+        ioff = carve(isz)
         ibuf = torch.empty((ioff[-1],), device=device, dtype=torch.int32)
-        fsz = [b * m, b * n, b * kmax]
-        foff = [0, r4(fsz[0]), r4(fsz[0]) + r4(fsz[1])]
-        fbuf = torch.empty((foff[2] + r4(fsz[2]),), device=device, dtype=torch.float32)
-        ipiece = lambda buf, k, *shape: buf[ioff[k]: ioff[k] + isz[k]].view(*shape)
-        m0, m1, mlist = ipiece(ibuf, 0, b, m), ipiece(ibuf, 1, b, n), ipiece(ibuf, 2, b, kmax, 2)
-        prune0 = ipiece(ibuf, 3, b, m) if do_point_pruning else None
-        prune1 = ipiece(ibuf, 4, b, n) if do_point_pruning else None
-        stop_nm = ipiece(ibuf, 5, 2, b)                     # [0] = stop, [1] = n_matches
-        ms0 = fbuf[foff[0]: foff[0] + fsz[0]].view(b, m)
-        ms1 = fbuf[foff[1]: foff[1] + fsz[1]].view(b, n)
-        mscore_list = fbuf[foff[2]: foff[2] + fsz[2]].view(b, kmax)
+        ipiece = lambda buf, off, sz, k, *shape: buf[off[k]: off[k] + sz[k]].view(*shape)
+        m0, m1, mlist = ipiece(ibuf, ioff, isz, 0, b, m), ipiece(ibuf, ioff, isz, 1, b, n), ipiece(ibuf, ioff, isz, 2, b, kmax, 2)
+        prune0_i32 = ipiece(ibuf, ioff, isz, 3, b, m) if do_point_pruning else None
+        prune1_i32 = ipiece(ibuf, ioff, isz, 4, b, n) if do_point_pruning else None
+        stop_nm = ipiece(ibuf, ioff, isz, 5, 3, b)              # [0] = stop, [1] = n_matches, [2] = status (LG_OK / LG_ERR_RANGE / LG_ERR_DEVICE)
+        fsz = [b * m, b * n, b * kmax, 0 if do_point_pruning else b * m, 0 if do_point_pruning else b * n]
+        foff = carve(fsz)
+        fbuf = torch.empty((foff[-1],), device=device, dtype=torch.float32)
+        ms0, ms1 = ipiece(fbuf, foff, fsz, 0, b, m), ipiece(fbuf, foff, fsz, 1, b, n)
+        mscore_list = ipiece(fbuf, foff, fsz, 2, b, kmax)
+        raw_mode = _raw is not False
+        m0_64 = m1_64 = mlist64 = stop64 = prune0 = prune1 = None
+        if not raw_mode:
+            lsz = [b * m, b * n, b * kmax * 2, b, b * m if do_point_pruning else 0, b * n if do_point_pruning else 0]
+            loff = carve(lsz)
+            lbuf = torch.empty((loff[-1],), device=device, dtype=torch.int64)
+            m0_64, m1_64 = ipiece(lbuf, loff, lsz, 0, b, m), ipiece(lbuf, loff, lsz, 1, b, n)
+            mlist64, stop64 = ipiece(lbuf, loff, lsz, 2, b, kmax, 2), ipiece(lbuf, loff, lsz, 3, b)
+            if do_point_pruning:
+                prune0, prune1 = ipiece(lbuf, loff, lsz, 4, b, m), ipiece(lbuf, loff, lsz, 5, b, n)
+            else:   # ref :616-617 (padding rows of a ragged batch: 0)
+                prune0, prune1 = ipiece(fbuf, foff, fsz, 3, b, m), ipiece(fbuf, foff, fsz, 4, b, n)
+        wire = _raw if torch.is_tensor(_raw) else None          # PairShardedMatcher: [pairs >= b][>= 2m + 2n + 1] int32 rows the engine packs itself
 
         log_assignment = None
         if self.return_log_assignment and m > 0 and n > 0:
@@ -420,12 +446,17 @@ class LightGlue(nn.Module):
         handle = self._get_engine(device)
         self._sync_weights(handle, device)
         ptr = lambda t: None if t is None or t.numel() == 0 else t.data_ptr()
+        flags = _cabi.LG_FLAG_EXT | (0 if do_point_pruning or conf.width_confidence <= 0 else _cabi.LG_FLAG_NO_PRUNING) | (_cabi.LG_FLAG_CHECK_FINITE if self.check_finite else 0)
         io = _cabi.LgForwardIO(
-            b, m, n, 0 if do_point_pruning or conf.width_confidence <= 0 else _cabi.LG_FLAG_NO_PRUNING,
+            b, m, n, flags,
             ptr(k0), ptr(k1), ptr(desc0), ptr(desc1), ptr(size0), ptr(size1),
             ptr(extra[0]), ptr(extra[1]), ptr(extra[2]), ptr(extra[3]),
-            ptr(m0), ptr(m1), ptr(ms0), ptr(ms1), stop_nm[0].data_ptr(), ptr(prune0), ptr(prune1),
-            ptr(mlist), ptr(mscore_list), stop_nm[1].data_ptr(), ptr(num0), ptr(num1), ptr(log_assignment))
+            ptr(m0), ptr(m1), ptr(ms0), ptr(ms1), stop_nm[0].data_ptr(), ptr(prune0_i32), ptr(prune1_i32),
+            ptr(mlist), ptr(mscore_list), stop_nm[1].data_ptr(), ptr(num0), ptr(num1), ptr(log_assignment),
+            ptr(m0_64), ptr(m1_64), ptr(mlist64), ptr(stop64),
+            ptr(prune0) if (do_point_pruning and not raw_mode) else None, ptr(prune1) if (do_point_pruning and not raw_mode) else None,
+            None if (do_point_pruning or raw_mode) else ptr(prune0), None if (do_point_pruning or raw_mode) else ptr(prune1),
+            ptr(wire), 0 if wire is None else wire.stride(0), stop_nm[2].data_ptr())
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             _cabi.check(_cabi.load().lg_engine_forward(handle, C.byref(io), C.c_void_p(stream)))
@@ -433,31 +464,16 @@ class LightGlue(nn.Module):
         if getattr(self, "_debug_step", -1) >= 0:  # test tap: the pipeline stopped early, outputs are not written
             torch.cuda.synchronize(device)
             return None
-        if _raw:
-            return {"matches0": m0, "matches1": m1, "matching_scores0": ms0, "matching_scores1": ms1, "stop": stop_nm[0]}
-        # ---- output assembly (ref :593-629).  Everything that does not need the ragged sizes is enqueued BEFORE
-        # the one host synchronisation of the forward, so the GPU is never idle waiting for Python.
-        i64 = ibuf.long()
-        m0_64, m1_64, mlist64 = ipiece(i64, 0, b, m), ipiece(i64, 1, b, n), ipiece(i64, 2, b, kmax, 2)
-        if do_point_pruning:
-            prune0, prune1 = ipiece(i64, 3, b, m), ipiece(i64, 4, b, n)
-        else:  # ref :616-617
-            pf = torch.full((b * (m + n),), float(conf.n_layers), device=device, dtype=torch.float32)
-            prune0, prune1 = pf[: b * m].view(b, m), pf[b * m:].view(b, n)
-            if num0 is not None:
-                prune0 = prune0 * (torch.arange(m, device=device)[None] < num0[:, None])
-            if num1 is not None:
-                prune1 = prune1 * (torch.arange(n, device=device)[None] < num1[:, None])
-        stop64 = ipiece(i64, 5, 2, b)[0]
+        if raw_mode:
+            return {"matches0": m0, "matches1": m1, "matching_scores0": ms0, "matching_scores1": ms1, "stop": stop_nm[0], "status": stop_nm[2]}
+        # ---- output assembly (ref :593-629): the engine has written every fixed-shape tensor; only the ragged lists need the host.
 
-        def assemble(host):   # host = [[stop per pair], [matches per pair]]
+        def assemble(host):   # host = [[stop per pair], [matches per pair], [status per pair]]
+            self._raise_on_status(host[2])
             counts = host[1]
             matches = [row[:c] for row, c in zip(mlist64.unbind(0), counts)]
             mscores = [row[:c] for row, c in zip(mscore_list.unbind(0), counts)]
-            if not do_early_stop and not do_point_pruning and m > 0 and n > 0 and not ragged:
-                stop_out = conf.n_layers if b == 1 else torch.full((b,), conf.n_layers, device=device, dtype=torch.long)
-            else:
-                stop_out = int(host[0][0]) if b == 1 else stop64
+            stop_out = int(host[0][0]) if b == 1 else stop64
             extra_out = {} if log_assignment is None else {"log_assignment": log_assignment}
             return {
                 **extra_out,
@@ -473,7 +489,7 @@ class LightGlue(nn.Module):
             }
 
         if _defer:   # the sizes travel to pinned host memory behind an event; nothing waits here
-            hbuf = torch.empty((2, b), dtype=torch.int32, pin_memory=True)
+            hbuf = torch.empty((3, b), dtype=torch.int32, pin_memory=True)
             hbuf.copy_(stop_nm, non_blocking=True)
             done = torch.cuda.Event()
             done.record(torch.cuda.current_stream(device))

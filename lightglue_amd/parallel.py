@@ -68,9 +68,10 @@ class PairShardedMatcher:
     ``forward_local(local_data, global_batch)`` takes the already-sharded local pairs.
     """
 
-    def __init__(self, matcher: Callable[[dict], dict], group=None):
+    def __init__(self, matcher: Callable[[dict], dict], group=None, always_gather: bool = False):
         self.matcher = matcher
         self.group = group
+        self.always_gather = always_gather   # issue the collective even in a world of one (bench.py measures its cost against no gather that way)
         self._src_cache: dict = {}
         self._side = None      # side stream of the result gather (created on first use on a GPU)
 
@@ -105,18 +106,20 @@ class PairShardedMatcher:
 
     __call__ = forward
 
-    def _row_source(self, shards: List[List[int]], per_rank: int, global_batch: int, device) -> torch.Tensor:
-        """gathered-buffer row of every pair of the batch (rank r's k-th row is pair shards[r][k]); built once per shard
-        assignment and kept on the device"""
+    def _row_source(self, shards: List[List[int]], per_rank: int, global_batch: int, device):
+        """(gathered-buffer row of every pair of the batch, destination pair of every gathered row or -1 for the padding rows of short shards):
+        rank r's k-th row is pair shards[r][k]; built once per shard assignment and kept on the device"""
         key = (tuple(tuple(sh) for sh in shards), per_rank, str(device))
         hit = self._src_cache.get(key)
         if hit is None:
             src = torch.empty(global_batch, dtype=torch.long)
+            dest = torch.full((len(shards) * per_rank,), -1, dtype=torch.int32)
             for r, sh in enumerate(shards):
                 src[torch.tensor(sh, dtype=torch.long)] = r * per_rank + torch.arange(len(sh))
+                dest[r * per_rank: r * per_rank + len(sh)] = torch.tensor(sh, dtype=torch.int32)
             if len(self._src_cache) > 64:
                 self._src_cache.clear()
-            hit = self._src_cache[key] = src.to(device)
+            hit = self._src_cache[key] = (src.to(device), dest.to(device))
         return hit
 
     def issue_local(self, local: dict, global_batch: int, shards: Optional[List[List[int]]] = None) -> "Pending":
@@ -130,14 +133,17 @@ class PairShardedMatcher:
         assert local["image0"]["keypoints"].shape[0] == nloc, "local shard size does not match the pair assignment"
         dev = local["image0"]["keypoints"].device
         raw = getattr(self.matcher, "forward_raw", None)
-        out = (raw(local) if raw is not None else self.matcher(local)) if nloc > 0 else None
-        # ---- pack [pairs_max][2m + 2n + 1] int32: matches0 | bits(scores0) | matches1 | bits(scores1) | stop
+        # ---- one row per pair, [pairs_max][2m + 2n + 1] int32: matches0 | bits(scores0) | matches1 | bits(scores1) | stop.  The HIP matcher's last
+        # kernel packs the rows itself (lg_forward_io.wire): no framework kernel between the forward and the collective.
         per_rank = (global_batch + world - 1) // world
         width = 2 * m + 2 * n + 1
         buf = torch.empty((per_rank, width), dtype=torch.int32, device=dev)
         if nloc < per_rank:
             buf[nloc:].zero_()
-        if nloc > 0:
+        if nloc > 0 and raw is not None and dev.type == "cuda":
+            raw(local, wire=buf)
+        elif nloc > 0:   # any other matcher with the dict contract (the CPU tests' stand-in): pack here
+            out = self.matcher(local)
             stop = out["stop"]
             stop_t = torch.full((nloc,), int(stop), dtype=torch.int32, device=dev) if not torch.is_tensor(stop) else stop.to(dev, torch.int32).reshape(nloc)
             as_i32 = lambda t: t if t.dtype is torch.int32 else t.to(torch.int32)
@@ -146,12 +152,12 @@ class PairShardedMatcher:
             buf[:nloc, 2 * m:2 * m + n] = as_i32(out["matches1"])
             buf[:nloc, 2 * m + n:2 * m + 2 * n] = out["matching_scores1"].to(torch.float32).contiguous().view(torch.int32)
             buf[:nloc, -1] = stop_t
-        if world == 1:
+        if world == 1 and not (self.always_gather and dist.is_initialized()):
             return Pending(self, buf[:nloc], None, None, m, n)
         # RCCL ("nccl") gathers device buffers directly; gloo (CPU tests, or a debugging run of several ranks
         # on one GPU) goes through host copies
         via_host = dist.get_backend(self.group) == "gloo" and buf.is_cuda
-        src = self._row_source(shards, per_rank, global_batch, dev)
+        src, dest = self._row_source(shards, per_rank, global_batch, dev)
         if buf.is_cuda and not via_host:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
@@ -162,13 +168,13 @@ class PairShardedMatcher:
                 dist.all_gather_into_tensor(gathered, buf, group=self.group)
                 done = torch.cuda.Event(); done.record(self._side)
             buf.record_stream(self._side); gathered.record_stream(self._side)
-            return Pending(self, gathered, src, done, m, n)
+            return Pending(self, gathered, src, done, m, n, dest)
         send = buf.cpu() if via_host else buf
         gathered = torch.empty((world * per_rank, width), dtype=torch.int32, device=send.device)
         dist.all_gather_into_tensor(gathered, send, group=self.group)
         if via_host:
             gathered = gathered.to(dev)
-        return Pending(self, gathered, src, None, m, n)
+        return Pending(self, gathered, src, None, m, n, dest)
 
     def forward_local(self, local: dict, global_batch: int, shards: Optional[List[List[int]]] = None) -> Dict[str, torch.Tensor]:
         return self.issue_local(local, global_batch, shards).wait()
@@ -189,14 +195,27 @@ class PairShardedMatcher:
 class Pending:
     """A result gather in flight.  `wait()` orders the current stream behind it and unpacks the full-batch tensors."""
 
-    def __init__(self, owner: PairShardedMatcher, gathered: torch.Tensor, src, done, m: int, n: int):
-        self.owner, self.gathered, self.src, self.done, self.m, self.n = owner, gathered, src, done, m, n
+    def __init__(self, owner: PairShardedMatcher, gathered: torch.Tensor, src, done, m: int, n: int, dest=None):
+        self.owner, self.gathered, self.src, self.done, self.m, self.n, self.dest = owner, gathered, src, done, m, n, dest
 
     def wait(self) -> Dict[str, torch.Tensor]:
         if self.done is not None:
             torch.cuda.current_stream(self.gathered.device).wait_event(self.done)
-        full = self.gathered if self.src is None else self.gathered.index_select(0, self.src)
-        m, n = self.m, self.n
+        m, n, g = self.m, self.n, self.gathered
+        if g.is_cuda:   # ONE engine kernel: row permutation, int64 widening, score bit patterns back to fp32 (lg_unpack_wire, include/lightglue_amd.h)
+            import ctypes as C
+            from . import _cabi
+            rows = g.shape[0] if self.src is None else self.src.shape[0]
+            new = lambda shape, dt: torch.empty(shape, dtype=dt, device=g.device)
+            out = {"matches0": new((rows, m), torch.int64), "matches1": new((rows, n), torch.int64), "matching_scores0": new((rows, m), torch.float32),
+                   "matching_scores1": new((rows, n), torch.float32), "stop": new((rows,), torch.int64)}
+            ptr = lambda t: None if t is None or t.numel() == 0 else t.data_ptr()
+            with torch.cuda.device(g.device):
+                _cabi.check(_cabi.load().lg_unpack_wire(ptr(g), g.stride(0), g.shape[0], m, n, ptr(self.dest) if self.src is not None else None,
+                                                        ptr(out["matches0"]), ptr(out["matching_scores0"]), ptr(out["matches1"]), ptr(out["matching_scores1"]),
+                                                        ptr(out["stop"]), C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)))
+            return out
+        full = g if self.src is None else g.index_select(0, self.src)
         return {"matches0": full[:, 0:m].long(), "matches1": full[:, 2 * m:2 * m + n].long(),
                 "matching_scores0": full[:, m:2 * m].contiguous().view(torch.float32),
                 "matching_scores1": full[:, 2 * m + n:2 * m + 2 * n].contiguous().view(torch.float32),

@@ -120,3 +120,45 @@ def test_plain_bench_command_launches_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl"]["world"] == 2 and len(d["rccl"]["ranks_seen"]) == 2
     assert d["parity"]["index_mismatches"] == 0 and d["parity"]["unexplained"] == 0
+
+
+def test_bench_config_4_two_ranks_on_one_gpu():
+    """an N-GPU run must be able to measure BASELINE cfg #4 (DISK 128-d, N = M = 4096, pair-sharded, RCCL gather).  Rehearsal of
+    the same entry point on one GPU at reduced N: two ranks share cuda:0 over gloo; the line names the config, carries the `rccl` block and a
+    roofline for the shape's dominant kernel."""
+    require_gpu()
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LG_BENCH_ONE_GPU="1", LG_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--config", "4", "--kpts", "512", "--pairs", "4", "--steps", "2", "--warmup", "2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl"]["world"] == 2 and d["config"]["descriptor_dim"] == 128 and "DISK 128-d" in d["config"]["baseline_config"]
+    assert d["roofline"]["kernel"] and d["roofline"]["frac"] > 0 and d["value"] > 0
+
+
+def test_bench_default_is_config_2_and_reports_the_gather_probe():
+    """The default workload stays BASELINE cfg #2 byte for byte (same seeds: the first four pairs ARE the reference fixture), and one GPU reports
+    what the world-of-one result gather costs a step."""
+    require_gpu()
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert d["metric"] == "image-pairs/s at N=M=1024, 9 layers; match-index parity vs ref" and d["config"]["pairs_per_gpu"] == 32 and d["config"]["keypoints"] == 1024
+    assert d["parity"]["pairs"] == 4 and d["parity"]["index_mismatches"] == 0
+    g = d["gather_probe_one_gpu"]
+    assert "error" not in g, g
+    assert g["matches_equal_plain_loop"] is True and g["ms_per_step_with_world1_gather"] > 0

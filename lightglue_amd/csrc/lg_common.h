@@ -18,6 +18,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// This library is written for ONE target.  Hard-wired below and in the kernels: the gfx9 buffer-descriptor word 0x00020000 (weight_rsrc, compact_rsrc),
+// the gfx9 s_waitcnt immediate layout (0x0F70 = vmcnt(0) only; lg_attention.hip, lg_tail.hip), v_mfma_f32_16x16x32_{f16,bf16}, v_permlane{16,32}_swap,
+// global_load_lds_dwordx4, and dynamic LDS up to 132 KB per workgroup (160 KB per CU).  Any other --offload-arch would miscompile or fail at launch
+// (ADVICE r04): refuse it here instead.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "lightglue_amd kernels are gfx950 (MI355X, CDNA4) only: build with --offload-arch=gfx950"
+#endif
+
 namespace lg {
 
 typedef __bf16 bf16_t;

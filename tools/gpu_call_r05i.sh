@@ -1,0 +1,11 @@
+#!/bin/bash
+# Round 5, call i: x rows of the whole tile stored without the per-row-tile branches (tree) against the branchy epilogue (-DLG_TAIL_STORE_ALL=0); parity tests on the tree.
+O=gpurun_out/r05i; rm -rf $O; mkdir -p $O
+export TMPDIR=/tmp
+line() { python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['kernel_ms_per_step']; print('$1', round(d['value']), round(d['ms_per_step'],3), {x: round(k[x],3) for x in ('attn_self','attn_cross','fused_tail') if x in k}, d['parity']['index_mismatches'], d['parity']['max_dscore'])"; }
+lib() { if [ "$1" = tree ]; then echo $PWD/lightglue_amd/liblightglue_amd.so; else echo $PWD/build_variants/liblightglue_amd_$1.so; fi; }
+for round in 1 2 3; do for v in branchy tree; do
+  LIGHTGLUE_AMD_LIB=$(lib $v) timeout 90 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-calibration --no-gather-probe 2>/dev/null | tail -1 | line $v
+done; done 2>&1 | tee $O/ab_cfg2.log
+for v in branchy tree; do echo "== $v"; LIGHTGLUE_AMD_LIB=$(lib $v) timeout 120 python tools/bench_configs.py "#3' " "#5' " 2>&1 | grep "^| #"; done | tee $O/ab_configs.log
+timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -n 4 -k "default_precision_parity or recorded_envelope or ragged or adaptive or pruned or pipeline_stages" > $O/tests_tree.log 2>&1; tail -3 $O/tests_tree.log

@@ -20,7 +20,7 @@ for f in ("bench.json", "bench_fast_attention.json", "bench_recipe_d.json"):
 PY
 LG_BENCH_BACKEND=gloo LG_BENCH_ONE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 2>&1 | tail -1 > $O/bench_2rank_gloo_one_gpu.json; python -c "
 import json; d = json.loads(open('$O/bench_2rank_gloo_one_gpu.json').read()); print('2 ranks on one GPU (gloo):', round(d['value']), d['rccl'])"
-rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-calibration > $O/trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-calibration --no-gather-probe > $O/trace.log 2>&1
 python tools/rocpd_stats.py $(find $O/trace -name "*.db" | head -1) $O/kernel_trace.md | head -16
 for c in cfg4_b32_n4096 adaptive_b16_n2048 b1_n1024; do
   rocprofv3 --kernel-trace --stats -d $O/trace_$c -o t -- python tools/trace_case.py $c > $O/trace_$c.log 2>&1

@@ -105,7 +105,13 @@ __global__ __launch_bounds__(DNT) void adapt_decide_kernel(AdaptArgs a) {
 // Memory ops are raw BUFFER loads / stores: a lane that has nothing to move gets an offset past the end of the buffer, for which the hardware
 // returns zeros / drops the store WITHOUT touching memory — 40 independent 16-byte loads per thread with no branch between them (a branch
 // around a load makes hipcc wait for it at the join, i.e. one exposed round trip per piece).
-constexpr int CROWS = 128;                     // rows per chunk
+#ifndef LG_COMPACT_ROWS
+#define LG_COMPACT_ROWS 128
+#endif
+constexpr int CROWS = LG_COMPACT_ROWS;         // rows per chunk.  64 was measured in round 5 (twice the work items, so that cfg #3' — 128 chunks of 128 rows on 256 CUs —
+                                               // fills the chip): SLOWER, 23.8 vs 17.9 us per launch, cfg #3' -1 % (profiles/r05j_*): the launch is a chain of per-item
+                                               // latencies (ticket, index loads, row loads, flag wait, stores), not a per-CU bandwidth limit
+constexpr int CXU = CROWS / 4, CTU = CROWS / 16;   // descriptor-row steps per wave, rotary-row steps per thread
 constexpr unsigned CSKIP = 0xFFFFFFF0u;        // offset no buffer reaches
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t compact_rsrc(float* p, long long bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)(bytes > 0xFFFFFF00LL ? 0xFFFFFF00LL : bytes), 0x00020000);
@@ -144,10 +150,10 @@ __global__ __launch_bounds__(256) void adapt_compact_kernel(AdaptArgs a) {
         if (tid < CROWS) sh_d[tid] = (myd >= 0 && myd != r0 + tid) ? myd : -1;   // (the loop head's barrier: the previous item's readers are done)
         __syncthreads();
         // descriptor rows: wave w, step u -> row 4u + w of the chunk, one 16-byte piece per lane (a whole 1 KB row per wave instruction)
-        u32x4 vx[32], vt[8]; int dx[32], dt[8];
+        u32x4 vx[CXU], vt[CTU]; int dx[CXU], dt[CTU];
         const unsigned xrow0 = (unsigned)(base + r0) * 1024u + (unsigned)lane * 16u;
 #pragma unroll
-        for (int u = 0; u < 32; ++u) {
+        for (int u = 0; u < CXU; ++u) {
             const int row = 4 * u + w;
             dx[u] = sh_d[row];
             vx[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, dx[u] >= 0 ? xrow0 + (unsigned)row * 1024u : CSKIP, 0, 0);
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(256) void adapt_compact_kernel(AdaptArgs a) {
         const int tt = tid & 127;
         const unsigned trow0 = (unsigned)(base + r0) * 128u + (unsigned)(tt & 7) * 16u;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < CTU; ++u) {
             const int row = 16 * u + (tt >> 3);
             dt[u] = sh_d[row];
             vt[u] = __builtin_amdgcn_raw_buffer_load_b128(rt, dt[u] >= 0 ? trow0 + (unsigned)row * 128u : CSKIP, 0, 0);
@@ -179,12 +185,14 @@ __global__ __launch_bounds__(256) void adapt_compact_kernel(AdaptArgs a) {
         if (sh_expired) continue;                // never expected (see above): leave this chunk's rows where they are rather than overwrite unread ones
         const unsigned xdst0 = (unsigned)base * 1024u + (unsigned)lane * 16u, tdst0 = (unsigned)base * 128u + (unsigned)(tt & 7) * 16u;
 #pragma unroll
-        for (int u = 0; u < 32; ++u) __builtin_amdgcn_raw_buffer_store_b128(vx[u], rx, dx[u] >= 0 ? xdst0 + (unsigned)dx[u] * 1024u : CSKIP, 0, 0);
+        for (int u = 0; u < CXU; ++u) __builtin_amdgcn_raw_buffer_store_b128(vx[u], rx, dx[u] >= 0 ? xdst0 + (unsigned)dx[u] * 1024u : CSKIP, 0, 0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) __builtin_amdgcn_raw_buffer_store_b128(vt[u], rt, dt[u] >= 0 ? tdst0 + (unsigned)dt[u] * 128u : CSKIP, 0, 0);
+        for (int u = 0; u < CTU; ++u) __builtin_amdgcn_raw_buffer_store_b128(vt[u], rt, dt[u] >= 0 ? tdst0 + (unsigned)dt[u] * 128u : CSKIP, 0, 0);
         if (myd >= 0) { a.ind[base + myd] = myv; prune[myv] += 1; }
     }
 }
+
+int compact_chunk_rows() { return CROWS; }
 
 hipError_t launch_adapt(const AdaptArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(adapt_decide_kernel, dim3(a.rs.B), dim3(DNT), 0, s, a);

@@ -311,7 +311,7 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
         for (int i = 0; i < 3; ++i) add(R * 256 * as);          // Q K VT
         add(R * 4); add(R * 4);                                 // IND DST
         for (int i = 0; i < 6; ++i) add((size_t)nB * 2 * 4);    // LEN LEN_ORIG LEN_OLD ACTIVE FINAL_LAYER RANGEF
-        add(R / 128 * 8 + 256);                                 // CFLAGS: 2B * max(cap0, cap1) / 128 ints <= 2 R / 128, + the error word
+        add(R / 32 * 8 + 256);                                  // CFLAGS: 2B * max(cap0, cap1) / chunk rows (>= 32) ints, + the error word and the work-item ticket
         add(R * 16); add(R * 16);                               // TAILDBG TAILDBG2 (16 bytes per row: [R / 64 workgroups][8 waves][8 stamps], or [R / 128][16 half-waves ...] of the split attention's taps)
         total += 4096;
         HIPCHK(hipMalloc(&e->ws, total));
@@ -342,7 +342,7 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
     e->LEN = (int*)take("LEN", (size_t)B * 2 * 4); e->LEN_ORIG = (int*)take("LEN_ORIG", (size_t)B * 2 * 4); e->LEN_OLD = (int*)take("LEN_OLD", (size_t)B * 2 * 4);
     e->ACTIVE = (int*)take("ACTIVE", (size_t)B * 4); e->FINAL_LAYER = (int*)take("FINAL_LAYER", (size_t)B * 4);
     e->RANGEF = (int*)take("RANGEF", (size_t)B * 4);
-    e->CFLAGS = (int*)take("CFLAGS", (size_t)2 * B * ((c0 > c1 ? c0 : c1) / 128) * 4 + 256); e->cflags_clean = false;
+    e->CFLAGS = (int*)take("CFLAGS", (size_t)2 * B * ((c0 > c1 ? c0 : c1) / compact_chunk_rows()) * 4 + 256); e->cflags_clean = false;
     e->TAILDBG = (long long*)take("TAILDBG", R * 16); e->TAILDBG2 = (long long*)take("TAILDBG2", R * 16);
     if (ar.used > e->ws_bytes) return fail(LG_ERR_STATE, "workspace carve overflow");
     return LG_OK;
@@ -818,7 +818,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
     int step = 0;
 #define STEP_DONE() do { if (e->debug_stop >= 0 && step >= e->debug_stop) return LG_OK; ++step; } while (0)
 
-    int* const device_err = e->CFLAGS + (size_t)2 * B * ((c0 > c1 ? c0 : c1) / 128);   // error word + compaction ticket behind the chunk flags (lg_adaptive.hip)
+    int* const device_err = e->CFLAGS + (size_t)2 * B * ((c0 > c1 ? c0 : c1) / compact_chunk_rows());   // error word + compaction ticket behind the chunk flags (lg_adaptive.hip)
     hipLaunchKernelGGL(init_state_kernel, dim3(64), dim3(256), 0, s, B, n0, n1, L, io->num0, io->num1, e->LEN, e->LEN_ORIG, e->LEN_OLD, e->ACTIVE, e->FINAL_LAYER,
                        do_prune ? io->prune0 : nullptr, do_prune ? io->prune1 : nullptr, e->RANGEF, device_err);
     int* const range_flag = check_finite ? e->RANGEF : nullptr;
@@ -996,7 +996,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
             ad.width_conf = (float)(1.0 - e->cfg.width_confidence);
             ad.pruning_min_kpts = e->cfg.pruning_min_kpts;
             ad.do_stop = do_stop; ad.do_prune = prune_now;
-            ad.compact_chunks = (c0 > c1 ? c0 : c1) / 128; ad.compact_flags = e->CFLAGS; ad.compact_err = device_err; ad.compact_ticket = device_err + 1;
+            ad.compact_chunks = (c0 > c1 ? c0 : c1) / compact_chunk_rows(); ad.compact_flags = e->CFLAGS; ad.compact_err = device_err; ad.compact_ticket = device_err + 1;
             if (prune_now && !e->cflags_clean) {   // fresh carve: whatever the arena held there must not look like an epoch
                 HIPCHK(hipMemsetAsync(e->CFLAGS, 0, (size_t)2 * B * ad.compact_chunks * 4 + 256, s));
                 e->cflags_clean = true;

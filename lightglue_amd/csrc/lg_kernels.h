@@ -159,13 +159,14 @@ struct AdaptArgs {
     float* X; float* cosb; float* sinb;
     int layer; float conf_thr; float depth_conf; float width_conf; int pruning_min_kpts;
     int do_stop, do_prune;
-    int compact_chunks;     // 128-row chunks per segment = max(cap0, cap1) / 128
+    int compact_chunks;     // chunks per segment = max(cap0, cap1) / compact_chunk_rows()
     int* compact_flags;     // [2B][compact_chunks] "chunk is in registers" flags, value = compact_epoch of the launch that set them
     int compact_epoch;      // > 0, different for every launch (never reset: stale flags of earlier launches compare unequal)
     int* compact_err;       // set to 1 if a bounded flag wait expired (never expected): the chunk's stores are SKIPPED and the forward reports LG_ERR_DEVICE in io->status
     int* compact_ticket;    // work-item counter of adapt_compact_kernel (reset by adapt_decide_kernel of the same launch_adapt)
 };
 hipError_t launch_adapt(const AdaptArgs& a, hipStream_t s);
+int compact_chunk_rows();   // rows per compaction work item (lg_adaptive.hip CROWS)
 
 // ---------------------------------------------------------------- assignment (lg_assign.hip)
 struct AssignArgs {

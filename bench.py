@@ -625,7 +625,7 @@ def main():
             # shader clock this box sustains under a matrix-core-dense load, measured right before the timed region: the pool's
             # boxes differ by up to ~20 % for one binary, and most of it is this clock
             "effective_mfma_clock_mhz": sustained_mhz, "sustained_dense_bf16_tflops": sustained_tflops,
-            "matches_per_pair": float(np.mean([(o > -1).sum().item() for o in out["matches0"]])) if "matches0" in out else None,
+            "matches_per_pair": float((out["matches0"].cpu().numpy() > -1).sum(axis=1).mean()) if "matches0" in out else None,   # (one copy: no framework kernels behind the timed region either)
             "value_synchronous_forward": sync_value,   # pairs/s with model(data) per step (host sync inside every forward), N = 1 only
             "rccl": rccl,
             "gather_probe_one_gpu": gather_probe,

@@ -5,7 +5,7 @@
 #   configs on one GPU, B = 1 latency, SuperPoint extractor
 O=gpurun_out/round; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -q > $O/gputests.log 2>&1; grep -E 'passed|failed|error' $O/gputests.log | tail -4   # (the full log is kept: a failure must be readable afterwards)
+python -m pytest tests -m gpu -q -n 4 > $O/gputests.log 2>&1; grep -E 'passed|failed|error' $O/gputests.log | tail -4   # (the full log is kept: a failure must be readable afterwards)
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err
 python bench.py --attention fp16 --no-cpu-baseline > $O/bench_fast_attention.json 2>> $O/bench.err
@@ -18,6 +18,12 @@ for f in ("bench.json", "bench_fast_attention.json", "bench_recipe_d.json"):
           "hbm frac", round(d["roofline_hbm"]["frac"], 3), "cpu", (d.get("cpu_baseline") or {}).get("value"), (d.get("cpu_baseline") or {}).get("reference_estimate_pairs_per_s"), d["kernel_ms_per_step"])
     print("   parity", d["parity"], d.get("parity_oracle"))
 PY
+for c in 3 4 5; do python bench.py --config $c --steps 5 --warmup 3 --no-cpu-baseline > $O/bench_cfg$c.json 2>> $O/bench.err; python - $c <<'PY'
+import json, sys
+d = json.load(open(f"gpurun_out/round/bench_cfg{sys.argv[1]}.json"))
+print("bench --config", sys.argv[1], round(d["value"], 1), "pairs/s", round(d["ms_per_step"], 2), "ms/step; roofline:", d["roofline"]["kernel"], round(d["roofline"]["frac"], 4), "; gather probe:", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in (d["gather_probe_one_gpu"] or {}).items() if k != "what"})
+PY
+done
 LG_BENCH_BACKEND=gloo LG_BENCH_ONE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 2>&1 | tail -1 > $O/bench_2rank_gloo_one_gpu.json; python -c "
 import json; d = json.loads(open('$O/bench_2rank_gloo_one_gpu.json').read()); print('2 ranks on one GPU (gloo):', round(d['value']), d['rccl'])"
 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-calibration --no-gather-probe > $O/trace.log 2>&1
@@ -35,4 +41,4 @@ find $O -name "*.db" -delete
 timeout 400 python tools/bench_configs.py 2>&1 | grep -v amdgpu.ids | tail -13; cp gpurun_out/configs.md $O/configs.md
 timeout 200 python tools/latency_b1.py 2>&1 | grep -v amdgpu.ids > $O/latency_b1.log; cat $O/latency_b1.log
 timeout 200 python tools/bench_superpoint.py 2>&1 | grep -v amdgpu.ids | tail -8 | tee $O/superpoint.log
-( python tools/tail_timing.py f16x3 1; python tools/tail_wall.py ) 2>&1 | grep -v amdgpu.ids | tee $O/tail_timing.log
+( python tools/tail_timing.py f16x3 1; python tools/tail_timing.py f16x3 5; python tools/tail_wall.py ) 2>&1 | grep -v amdgpu.ids | tee $O/tail_timing.log

@@ -876,7 +876,16 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 ProjArgs pj = make_proj(i, blk);
                 pj.dbg = (e->tail_timing == 2 && blk == 0) ? e->TAILDBG : nullptr;
                 TRY(prof_begin(e, blk == 0 ? PC_GEMM_QKV_SELF : PC_GEMM_QKV_CROSS, s));
-                if (fuse_prep && i == 0 && blk == 0) { pj.rs = rs_all; HIPCHK(launch_proj_first(prec, ap, pj, p, s)); }   // rs_all: what prep covers (pairs with an empty image too)
+                if (fuse_prep && i == 0 && blk == 0) {
+                    pj.rs = rs_all;                                 // rs_all: what prep covers (pairs with an empty image too)
+                    if (launch_proj_first(prec, ap, pj, p, s) != hipSuccess) {
+                        //  e.g. the 80 KB of dynamic LDS refused: the separate preparation kernel + the standard projection instead — bit-identical
+                        (void)hipGetLastError();
+                        HIPCHK(launch_prep(p, s));
+                        pj.rs = rs_act;
+                        HIPCHK(launch_proj(prec, ap, pj, s));
+                    }
+                }
                 else HIPCHK(launch_proj(prec, ap, pj, s));
                 TRY(prof_end(e, s));
             }

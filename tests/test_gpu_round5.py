@@ -137,3 +137,27 @@ def test_no_framework_kernels_between_engine_launches():
     foreign = [k for k in kernels if any(tag in k for tag in ("at::", "at_cuda", "c10::", "rocprim", "hipcub", "elementwise", "Elementwise"))]
     ours = [k for k in kernels if "lg::" in k or "anonymous namespace" in k]
     assert len(ours) >= 20 and not foreign, f"framework kernels on the product path: {sorted(set(foreign))}"
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_seed_sweep_adaptive_parity(seed):
+    """The adaptive path (early stop + point pruning on the device: decide / compact / un-prune) on weights and data no fixture holds: recipe C
+    (pairs stop at mixed depths and prune), N = 1100 / M = 900 with the pruning threshold lowered to 512 so that both images prune.  Against the
+    oracle: same stop layer, same prune counters, indices / scores under the usual bar."""
+    require_gpu()
+    torch.set_num_threads(8)
+    wseed, dseed = 200 + seed, 9100 + 17 * seed
+    sd = synth.make_state_dict(wseed, recipe="C")
+    data = synth.make_batch(dseed, 1, 1100, 900)
+    conf_kw = dict(pruning_min_kpts=512)
+    ref = O.forward(sd, O.make_conf(**conf_kw), data, backend="torch")
+    gold = {k: np.asarray(ref[k]) for k in ("matches0", "matches1", "matching_scores0", "matching_scores1", "prune0", "prune1")}
+    model = gpu_util.make_model(sd, "f16x3", **conf_kw)
+    out = model(gpu_util.to_torch(data))
+    torch.cuda.synchronize()
+    assert int(out["stop"]) == int(ref["stop"][0])
+    np.testing.assert_array_equal(out["prune0"].cpu().numpy(), gold["prune0"])
+    np.testing.assert_array_equal(out["prune1"].cpu().numpy(), gold["prune1"])
+    case = {"conf": conf_kw, "prune_th": 512, "recipe": "C", "wseed": wseed, "dseed": dseed, "n": 1100, "m": 900, "B": 1, "dim": 256}
+    flips = assert_parity_with_explained_flips(out, gold, case, sd, data, score_tol=SCORE_TOL)
+    assert sum(flips) <= 2, flips

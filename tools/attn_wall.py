@@ -11,9 +11,13 @@ from lightglue_amd import synthetic as synth
 sd = synth.make_state_dict(0, recipe="A")
 model = gpu_util.make_model(sd, "f16x3", depth_confidence=-1, width_confidence=-1)
 data = gpu_util.to_torch(synth.make_batch(1, 32, 1024, 1024))
+import os
+NW = int(os.environ.get("LG_ATTN_WALL_NW", "8"))      # waves per workgroup of the kernel under test (split attention: 8; attn_dma_kernel: 4)
+for kv in os.environ.get("LG_BENCH_OPTS", "").split():
+    k, v = kv.split("="); model.set_option(k, int(v))
 for _ in range(3): model(data)
 model.set_option("tail_timing", 3); model(data); torch.cuda.synchronize()
-d = model.debug_read("TAILDBG", np.int64).reshape(-1, 4, 8)
+d = model.debug_read("TAILDBG", np.int64).reshape(-1, NW, 8)
 d = d[d[:, 0, 7] == 1][:, 0, :]          # wave 0 of each workgroup
 t0, t1, cyc, hw, xcc = d[:, 0], d[:, 1], d[:, 2], d[:, 3], d[:, 4]
 base = t0.min()

@@ -564,7 +564,11 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_dma_kernel(AttnArgs a) {
 // than 4 waves x 32 rows (172 VGPRs, two waves per SIMD).  Lost: a cross-tile software pipeline (S(t+1) MFMAs interleaved with the
 // softmax VALU of tile t inside each wave via sched_group_barrier: bit-identical, +7 % time).  SQ counters of the kernel: matrix
 // pipe 54 % busy, waves 42 % issue-stalled, 25 % parked; timing ablations: no DMA -9 %, no exponentials -4 % — LAB_NOTES.md.
-template <int QT, int NW, int PR = 0>
+// Round 6: a PING-PONG form (the two waves a workgroup has on a SIMD half a tile apart — one multiplies while the other runs its softmax —, two barriers per
+// tile, K(t + 1) requested behind the first and V(t + 1) behind the second; bit-identical; tools/experiments/attn_pingpong.patch) took MORE cycles per workgroup
+// (64.9k vs 63.5k) and +2 ... +6 % time; priorities by phase or none at all: noise.  The kernel is not bound by when its waves do what: inside a forward the chip
+// sits at its 1.35 kW power limit and runs this kernel at 1.64 GHz of 2.4 (profiles/r06b_attn_wall_clock.log) — what moves it is energy per tile.
+template <int QT, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 2) void attn_split_kernel(AttnArgs a) {
     typedef TagF16 Tag;
     typedef f16_t T;
@@ -653,13 +657,13 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_split_kernel(AttnArgs a)
 #ifdef LG_ATTN_TIMING
     long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
 #endif
-#ifdef LG_ATTN_WALL    // experiment: workgroup life span on the 100 MHz wall clock + shader cycles -> the clock the kernel ran at (tools/attn_wall.py)
+#ifdef LG_ATTN_WALL    // profiling build: workgroup life span on the 100 MHz wall clock + shader cycles -> the clock the kernel ran at (tools/attn_wall.py)
     const long long wall0 = wall_clock64(), cyc0 = clock64();
 #endif
     for (int tile = 0; tile < ntiles; ++tile) {
         const int kv0 = tile * ABK;
         const char* bK = smem + (tile & 1) * BUFB;
-        if (PR == 0 && (tile & 3) == 0) {   // wave priority by progress, see attn_dma_kernel
+        if ((tile & 3) == 0) {   // wave priority by progress, see attn_dma_kernel
             const int q = (tile * 4) / ntiles;
             if (q == 0) __builtin_amdgcn_s_setprio(3); else if (q == 1) __builtin_amdgcn_s_setprio(2); else if (q == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         }
@@ -714,7 +718,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_split_kernel(AttnArgs a)
         ATT_TICK(1);
 
         // ---- S^T - m_run: per k-chunk and pair of key tiles, three products over 2 x QT independent accumulators
-        if (PR == 1) __builtin_amdgcn_s_setprio(2);
         f32x4 s[4][QT];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
@@ -743,7 +746,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_split_kernel(AttnArgs a)
             __builtin_amdgcn_sched_barrier(0);
         }
         ATT_TICK(2);
-        if (PR == 1) __builtin_amdgcn_s_setprio(0);
         if (kv0 + ABK > kvlen) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt)
@@ -794,7 +796,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_split_kernel(AttnArgs a)
             l_run[qt] += rs0 + rs1;
         }
         ATT_TICK(4);
-        if (PR == 1) __builtin_amdgcn_s_setprio(2);
         // ---- O^T += V^T P^T with P = Ph + Pl (both f16; the residual p - Ph is exact in fp32): three products per (d tile, query tile)
         u32x4 ph[2][QT], pl[2][QT];
 #pragma unroll
@@ -852,293 +853,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_split_kernel(AttnArgs a)
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// PING-PONG form of attn_split_kernel<1, 8> (round 6).  Same tiles, same fragment layouts, the same sequence of arithmetic per
-// query row (bit-identical output) — what changes is WHEN a wave does which phase of a key tile.  The two waves a workgroup has on
-// one SIMD (w and w + 4) run half a tile apart, so that one is in a matrix phase while the other is in its softmax:
-//
-//        barrier A(t)                      barrier B(t)                                         barrier A(t + 1)
-//   early (waves 0-3):  S(t) = K(t) Q^T        |   softmax(t),  O += V(t) P(t)                       |
-//   late  (waves 4-7):  O += V(t-1) P(t-1)     |   S(t) = K(t) Q^T,  softmax(t)                      |
-//
-// With ONE barrier per tile (attn_split_kernel) both waves of a SIMD leave the barrier together, multiply together and reach the
-// softmax together: 3 072 matrix-pipe cycles and ~1 900 cycles of VALU issue per tile and SIMD were paid one after the other (5 200
-// measured).  Buffers: K(t) is read in interval t only, V(t) in the second half of interval t (early) and the first half of
-// interval t + 1 (late) — so K(t + 1) is requested right after A(t) and V(t + 1) right after B(t), into the buffers whose last
-// readers those barriers have just retired: still two buffers, 64 KB, two workgroups per CU.  Each wave carries its own pieces:
-// the wait in front of A(t) is vmcnt(2) (K(t) landed, V(t) may still fly), in front of B(t) vmcnt(2) again (V(t) landed, K(t + 1) flies).
-template <int PRIO>
-__global__ __launch_bounds__(512, 4) void attn_split_pp_kernel(AttnArgs a) {
-    typedef TagF16 Tag;
-    typedef f16_t T;
-    constexpr int NT = 512, ABM = 128, ROWB = 128, TILEB = 64 * ROWB, BUFB = 4 * TILEB;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int ntile = gridDim.x >> 2;
-    const int v = xcd_remap(blockIdx.x, gridDim.x);
-    const int head = v / ntile;
-    const TileLoc t = locate_tile(a.rs, v - head * ntile, ABM);
-    const int qlen = a.rs.len[t.seg];
-    if (t.r0 >= qlen) return;
-    if (a.rs.active && !a.rs.active[t.pair]) return;
-    const int kvseg = a.cross ? (t.seg ^ 1) : t.seg;
-    const int kvlen = a.rs.len[kvseg];
-    const long long kvbase = seg_row_base(a.rs, kvseg);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, g = lane >> 4;
-    const long long R = a.R, PL = a.plane;
-    const T* Q = static_cast<const T*>(a.q);
-    const T* Kp = static_cast<const T*>(a.cross ? a.q : a.k);
-    const T* Vt = static_cast<const T*>(a.vt);
-
-    if (kvlen == 0) {  // ref :114-115: empty key set -> zeros
-        for (int i = tid; i < ABM * 16; i += NT) {
-            const int row = i >> 4, c4 = i & 15;
-            if (t.r0 + row < qlen) *reinterpret_cast<f32x4*>(a.ctx + (t.grow0 + row) * 256LL + head * 64 + c4 * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        return;
-    }
-
-    // DMA source offsets (elements), per lane: wave w brings piece w (rows 8w .. 8w + 7) of each of the four tiles
-    const int prow = lane >> 3, pslot = lane & 7;
-    const int prw = wave * 8 + prow;
-    const int koff = prw * 64 + ((pslot ^ (((prw >> 1) & 1) | (((prw >> 3) & 3) << 1))) << 3);          // inverse of k_off<128>
-    const int voff = (pslot ^ ((prw >> 1) & 7)) << 3;                                                    // inverse of lds_off<128>
-    const T* kseg = Kp + ((long long)head * R + kvbase) * 64 + koff;
-    const T* vrow = Vt + ((long long)head * 64 + prw) * R + kvbase + voff;
-    auto dma_k = [&](int buf, int kv0) {
-        char* dst = smem + buf * BUFB + wave * 1024;
-        const T* ks = kseg + (long long)kv0 * 64;
-        lds_dma16(ks, dst); lds_dma16(ks + PL, dst + TILEB);
-    };
-    auto dma_v = [&](int buf, int kv0) {
-        char* dst = smem + buf * BUFB + 2 * TILEB + wave * 1024;
-        const T* vs = vrow + kv0;
-        lds_dma16(vs, dst); lds_dma16(vs + PL, dst + TILEB);
-    };
-    dma_k(0, 0); dma_v(0, 0);
-
-    int kfo[2], vfo[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        kfo[c] = k_off<ROWB>(8 * (lr >> 2) + (lr & 3), c * 4 + g);
-        vfo[c] = 2 * TILEB + lds_off<ROWB>(lr, 4 * c + g);
-    }
-    u32x4 qh[2], ql[2];
-    {
-        const long long grow = (long long)t.grow0 + wave * 16 + lr;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const T* src = Q + ((long long)head * R + grow) * 64 + c * 32 + g * 8;
-            qh[c] = *reinterpret_cast<const u32x4*>(src);
-            ql[c] = *reinterpret_cast<const u32x4*>(src + PL);
-        }
-    }
-    f32x4 o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = 0.f, l_run = 0.f;          // finite: the accumulators start at -m_run; the first tile always re-bases
-    const int ntiles = (kvlen + ABK - 1) / ABK;
-    const bool partial = (kvlen & (ABK - 1)) != 0;
-
-    f32x4 s[4];
-    u32x4 ph[2], pl[2];
-#ifdef LG_ATTN_WALL
-    const long long wall0 = wall_clock64(), cyc0 = clock64();
-#endif
-
-    // ---- S^T - m_run for key tile in buffer bK (fragment reads one group ahead, as in attn_split_kernel; no V prefetch at the end:
-    // V(t) is only published by barrier B)
-    auto phase_s = [&](const char* bK) {
-        u32x4 fh[2][2], fl[2][2];
-        auto load_k = [&](int grp, u32x4 (&h)[2], u32x4 (&l)[2]) {
-            const int c = grp >> 1, kp = grp & 1;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int kt = 2 * kp + j;
-                const char* src = bK + kfo[c] + (32 * (kt >> 1) + 4 * (kt & 1)) * ROWB;
-                h[j] = *reinterpret_cast<const u32x4*>(src);
-                l[j] = *reinterpret_cast<const u32x4*>(src + TILEB);
-            }
-        };
-        load_k(0, fh[0], fl[0]);
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) s[kt] = f32x4{-m_run, -m_run, -m_run, -m_run};
-#pragma unroll
-        for (int grp = 0; grp < 4; ++grp) {
-            const int c = grp >> 1, kp = grp & 1;
-            if (grp < 3) load_k(grp + 1, fh[(grp + 1) & 1], fl[(grp + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            const u32x4 (&kh)[2] = fh[grp & 1];
-            const u32x4 (&kl)[2] = fl[grp & 1];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) mma_chunk<Tag>(s[2 * kp + j], kh[j], ql[c]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) mma_chunk<Tag>(s[2 * kp + j], kl[j], qh[c]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) mma_chunk<Tag>(s[2 * kp + j], kh[j], qh[c]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // ---- online softmax on d = score - m_run (deferred rescale; the first tile always re-bases) and the hi / lo split of P
-    auto phase_sm = [&](int tile) {
-        const int kv0 = tile * ABK;
-        if (kv0 + ABK > kvlen) {
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (kv0 + 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r >= kvlen) s[kt][r] = -INFINITY;
-        }
-        const float t0 = vmax3(s[0][0], s[0][1], s[0][2]), t1 = vmax3(s[0][3], s[1][0], s[1][1]);
-        const float t2 = vmax3(s[1][2], s[1][3], s[2][0]), t3 = vmax3(s[2][1], s[2][2], s[2][3]);
-        const float t4 = vmax3(s[3][0], s[3][1], s[3][2]);
-        const float mx = vmax2(vmax3(t0, t1, t2), vmax3(t3, t4, s[3][3]));
-        const float dmax = xor32_max(xor16_max(mx));              // finite: every tile holds >= 1 live key
-        const bool grew = tile == 0 || dmax > 8.f;
-        if (__any(grew)) {
-            const float shift = tile == 0 ? dmax : (dmax > 8.f ? dmax : 0.f);
-            const float alpha = tile == 0 ? 0.f : __builtin_amdgcn_exp2f(-shift);
-            l_run *= alpha;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
-            m_run += shift;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[kt] -= shift;
-        }
-        float rs0 = 0.f, rs1 = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            const float p0 = __builtin_amdgcn_exp2f(s[kt][0]), p1 = __builtin_amdgcn_exp2f(s[kt][1]);
-            const float p2 = __builtin_amdgcn_exp2f(s[kt][2]), p3 = __builtin_amdgcn_exp2f(s[kt][3]);
-            s[kt][0] = p0; s[kt][1] = p1; s[kt][2] = p2; s[kt][3] = p3;
-            rs0 += p0 + p2; rs1 += p1 + p3;
-        }
-        l_run += rs0 + rs1;
-#pragma unroll
-        for (int tp = 0; tp < 2; ++tp) split8_f16<true>(s[2 * tp], s[2 * tp + 1], ph[tp], pl[tp]);
-    };
-    // ---- O^T += V^T P^T for the V^T tiles of buffer bK
-    auto phase_pv = [&](const char* bK) {
-        u32x4 fh[2][2], fl[2][2];
-        auto load_v = [&](int grp, u32x4 (&h)[2], u32x4 (&l)[2]) {
-            const int tp = grp >> 1, dp = grp & 1;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const char* src = bK + vfo[tp] + (2 * dp + j) * 16 * ROWB;
-                h[j] = *reinterpret_cast<const u32x4*>(src);
-                l[j] = *reinterpret_cast<const u32x4*>(src + TILEB);
-            }
-        };
-        load_v(0, fh[0], fl[0]);
-#pragma unroll
-        for (int grp = 0; grp < 4; ++grp) {
-            const int tp = grp >> 1, dp = grp & 1;
-            if (grp < 3) load_v(grp + 1, fh[(grp + 1) & 1], fl[(grp + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            const u32x4 (&vh)[2] = fh[grp & 1];
-            const u32x4 (&vl)[2] = fl[grp & 1];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) mma_chunk<Tag>(o[2 * dp + j], vh[j], pl[tp]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) mma_chunk<Tag>(o[2 * dp + j], vl[j], ph[tp]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) mma_chunk<Tag>(o[2 * dp + j], vh[j], ph[tp]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // barrier A(tile): K(tile) complete for everyone; a partial LAST tile also needs V(tile) now (its dead key columns are zeroed
-    // between A and B by all waves: 0 x stale NaN must not happen)
-    auto barrier_a = [&](int tile) {
-        const bool fix = partial && tile == ntiles - 1;
-        // tile 0: vmcnt(0) — the Q fragment loads were issued BEHIND K(0) / V(0), and hipcc's own waits for them (it cannot see the DMAs) would
-        // otherwise sit behind K(1)'s issue and cover it as well (in-order counter)
-        if (fix || tile == 0) __builtin_amdgcn_s_waitcnt(0x0070); else __builtin_amdgcn_s_waitcnt(0x0072);    // vmcnt(0) / vmcnt(2), lgkmcnt(0)
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (fix) {
-            char* bK = smem + (tile & 1) * BUFB;
-#pragma unroll
-            for (int i = 0; i < 1024 / NT; ++i) {         // 512 16-byte chunks per plane
-                const int c = (tid + NT * i) & 511, plane = (tid + NT * i) >> 9, row = c >> 3, slot = c & 7;
-                u32x4* p = reinterpret_cast<u32x4*>(bK + (2 + plane) * TILEB + lds_off<ROWB>(row, slot));
-                *p = mask_tail<Tag>(*p, kvlen - (tile * ABK + slot * 8));
-            }
-        }
-        dma_k((tile + 1) & 1, tile + 1 < ntiles ? (tile + 1) * ABK : tile * ABK);     // not branched (see attn_split_kernel): the last tile re-fetches itself
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto barrier_b = [&](int tile) {
-        __builtin_amdgcn_s_waitcnt(0x0072);                // vmcnt(2): my V(tile) pieces landed; lgkmcnt(0): my fix-up stores, if any
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        dma_v((tile + 1) & 1, tile + 1 < ntiles ? (tile + 1) * ABK : tile * ABK);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    if (wave < 4) {
-        if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
-        for (int tile = 0; tile < ntiles; ++tile) {
-            const char* bK = smem + (tile & 1) * BUFB;
-            barrier_a(tile);
-            if (PRIO == 3) __builtin_amdgcn_s_setprio(2);
-            phase_s(bK);
-            barrier_b(tile);
-            if (PRIO == 3) __builtin_amdgcn_s_setprio(0);
-            phase_sm(tile);
-            if (PRIO == 3) __builtin_amdgcn_s_setprio(2);
-            phase_pv(bK);
-        }
-    } else {
-        if (PRIO == 1 || PRIO == 2) __builtin_amdgcn_s_setprio(1);
-        for (int tile = 0; tile < ntiles; ++tile) {
-            barrier_a(tile);
-            if (PRIO == 3) __builtin_amdgcn_s_setprio(2);
-            if (tile > 0) phase_pv(smem + ((tile - 1) & 1) * BUFB);
-            barrier_b(tile);
-            phase_s(smem + (tile & 1) * BUFB);
-            if (PRIO == 3) __builtin_amdgcn_s_setprio(0);
-            phase_sm(tile);
-        }
-        if (PRIO == 3) __builtin_amdgcn_s_setprio(2);
-        phase_pv(smem + ((ntiles - 1) & 1) * BUFB);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last (redundant) fetches must have landed before this wave's LDS can be released
-#ifdef LG_ATTN_WALL
-    if (a.dbg && lane == 0) {
-        long long* d = a.dbg + ((long long)blockIdx.x * 8 + wave) * 8;
-        d[0] = wall0; d[1] = wall_clock64(); d[2] = clock64() - cyc0; d[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4); d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 20); d[6] = ntiles; d[7] = 1;
-    }
-#endif
-    {
-        float l = l_run;
-        l = xor32_sum(xor16_sum(l));
-        const float inv = 1.f / l;
-        const int qrow = t.r0 + wave * 16 + lr;
-        if (qrow < qlen) {
-            float* dst = a.ctx + (t.grow0 + wave * 16 + lr) * 256LL + head * 64 + g * 4;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(dst + dt * 16) = o[dt] * inv;
-        }
-    }
-}
-
-template <int PRIO> static hipError_t launch_attn_split_pp(const AttnArgs& a, hipStream_t s) {
+template <int QT, int NW> static hipError_t launch_attn_split(const AttnArgs& a, hipStream_t s) {
     if (a.plane <= 0) return hipErrorInvalidValue;
     constexpr int smem = 2 * 4 * 64 * 128;
-    auto kern = attn_split_pp_kernel<PRIO>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return e;
-    const int tiles = a.rs.B * (a.rs.cap0 + a.rs.cap1) / 128;
-    hipLaunchKernelGGL(kern, dim3(tiles * 4), dim3(512), smem, s, a);
-    return hipGetLastError();
-}
-
-template <int QT, int NW, int PR = 0> static hipError_t launch_attn_split(const AttnArgs& a, hipStream_t s) {
-    if (a.plane <= 0) return hipErrorInvalidValue;
-    constexpr int smem = 2 * 4 * 64 * 128;
-    auto kern = attn_split_kernel<QT, NW, PR>;
+    auto kern = attn_split_kernel<QT, NW>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     const int tiles = a.rs.B * (a.rs.cap0 + a.rs.cap1) / (16 * QT * NW);
@@ -1169,18 +887,7 @@ hipError_t launch_attention(int attn_prec, const AttnArgs& a, hipStream_t s) {
         case PREC_F32: return launch_attn_t<TagF32, 2>(a, s);
         case PREC_BF16: if (a.dma && rpw == 32) return launch_attn_dma<TagBF16>(a, s); return rpw == 64 ? launch_attn_t<TagBF16, 4>(a, s) : rpw == 16 ? launch_attn_t<TagBF16, 1>(a, s) : launch_attn_t<TagBF16, 2>(a, s);
         case PREC_F16: if (a.dma && rpw == 32) return launch_attn_dma<TagF16>(a, s); return rpw == 64 ? launch_attn_t<TagF16, 4>(a, s) : rpw == 16 ? launch_attn_t<TagF16, 1>(a, s) : launch_attn_t<TagF16, 2>(a, s);
-        case PREC_F16X3: {
-            if (rpw == 16) return launch_attn_split<1, 4>(a, s);
-            switch (a.pingpong) {
-                case 1: return launch_attn_split_pp<0>(a, s);
-                case 2: return launch_attn_split_pp<1>(a, s);
-                case 3: return launch_attn_split_pp<2>(a, s);
-                case 4: return launch_attn_split_pp<3>(a, s);
-                case 5: return launch_attn_split<1, 8, 1>(a, s);
-                case 6: return launch_attn_split<1, 8, 2>(a, s);
-            }
-            return launch_attn_split<1, 8>(a, s);
-        }   // 64-row workgroups for under-filled grids, else 128-row ones (8 waves x 16 rows)
+        case PREC_F16X3: return rpw == 16 ? launch_attn_split<1, 4>(a, s) : launch_attn_split<1, 8>(a, s);   // 64-row workgroups for under-filled grids, else 128-row ones (8 waves x 16 rows)
     }
     return hipErrorInvalidValue;
 }

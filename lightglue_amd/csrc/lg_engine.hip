@@ -111,7 +111,6 @@ struct lg_engine {
     int tail_timing = 0; long long* TAILDBG = nullptr; long long* TAILDBG2 = nullptr;
     int* CFLAGS = nullptr; int compact_epoch = 0; bool cflags_clean = false;   // compaction chunk flags [2B][cap / 128] + 1 error word (lg_adaptive.hip)
     int tail_row_tiles = 0;   // option "tail_row_tiles": 16-row tiles per fused-tail workgroup; 0 = by grid fill (4 | 2 | 1)
-    int attn_pp = 0;   // option "attn_pp": ping-pong split attention (0 off; 1..4 priority variants)
     bool attn_auto_rows = true;   // small grids: 16 query rows per attention wave (twice the workgroups); off once "attn_rows" is set
     // ---- workspace
     void* ws = nullptr; size_t ws_bytes = 0;
@@ -600,7 +599,6 @@ int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
     if (std::strcmp(key, "fused_next") == 0) { e->fused_next = value != 0; return LG_OK; }
     if (std::strcmp(key, "fused_prep") == 0) { e->fused_prep = value != 0; return LG_OK; }
     if (std::strcmp(key, "attn_dma") == 0) { e->attn_dma = value != 0; return LG_OK; }
-    if (std::strcmp(key, "attn_pp") == 0) { if (value < 0 || value > 6) return fail(LG_ERR_INVALID, "attn_pp must be 0..6"); e->attn_pp = value; return LG_OK; }
     if (std::strcmp(key, "attn_rows") == 0) { if (value != 16 && value != 32 && value != 64) return fail(LG_ERR_INVALID, "attn_rows must be 16, 32 or 64"); e->attn_rows = value; e->attn_auto_rows = false; return LG_OK; }
     if (std::strcmp(key, "tail_row_tiles") == 0) { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(LG_ERR_INVALID, "tail_row_tiles must be 0 (automatic), 1, 2 or 4"); e->tail_row_tiles = value; return LG_OK; }
     if (std::strcmp(key, "profile_only") == 0) { e->prof_only = value; return LG_OK; }   // kernel class index, -1 = all classes
@@ -897,7 +895,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                 AttnArgs at{};
                 at.rs = rs_act; at.q = e->Q; at.k = e->K; at.vt = e->VT; at.plane = qkv_plane; at.ctx = e->CTX; at.R = R; at.cross = blk;
                 at.dbg = (e->tail_timing == 3 && blk == 0) ? e->TAILDBG : nullptr;
-                at.rows_per_wave = (e->attn_auto_rows && R / 128 * 4 < 256) ? 16 : e->attn_rows; at.dma = e->attn_dma ? 1 : 0; at.pingpong = e->attn_pp;   // fewer 128-row workgroups than CUs: 64-row ones
+                at.rows_per_wave = (e->attn_auto_rows && R / 128 * 4 < 256) ? 16 : e->attn_rows; at.dma = e->attn_dma ? 1 : 0;   // fewer 128-row workgroups than CUs: 64-row ones
                 TRY(prof_begin(e, blk == 0 ? PC_ATTN_SELF : PC_ATTN_CROSS, s));
                 HIPCHK(launch_attention(ap, at, s));
                 TRY(prof_end(e, s));

@@ -107,7 +107,6 @@ struct AttnArgs {
     long long* dbg;   // profiling builds (-DLG_ATTN_TIMING) only: [blocks][4 waves][8] phase clock sums
     int rows_per_wave;   // 16, 32 or 64 query rows per wave (see launch_attention)
     int dma;             // 16-bit, 32 rows per wave: the LDS-DMA kernel (attn_dma_kernel)
-    int pingpong;        // split attention, 128-row workgroups: 0 = one barrier per tile (attn_split_kernel), 1.. = attn_split_pp_kernel priority variants
 };
 hipError_t launch_attention(int attn_prec, const AttnArgs& a, hipStream_t s);
 

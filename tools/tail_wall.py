@@ -24,6 +24,7 @@ base = t0.min(); life = (t1 - t0) / 100.0
 assert 0 < t1.max() - base < 10_000_000, ("implausible span", int(t1.max() - base))   # (an unmasked id field once made this 1e14 ticks)
 print("workgroups", len(d), " kernel span %.1f us" % ((t1.max() - base) / 100.0), " (the LAST tail launch of the forward: no fused projection)")
 print("workgroup life us: median %.1f p10 %.1f p90 %.1f max %.1f; stamps 0->5 median %.0f cycles" % (np.median(life), np.percentile(life, 10), np.percentile(life, 90), life.max(), np.median(cyc)))
+print("shader clock while a tail workgroup lives (stamp cycles / wall life; the stamps span slightly less than the life): median %.0f MHz" % np.median(cyc / life))
 ts = np.linspace(0, t1.max() - base, 60)
 print("live workgroups at 60 equally spaced times:", [int((((t0 - base) <= t) & ((t1 - base) > t)).sum()) for t in ts])
 u = np.unique(cu); gaps = []; per = []

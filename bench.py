@@ -294,12 +294,14 @@ def batch_kwargs(recipe):
     return dict(synthetic.RECIPE_D_DATA) if recipe == "D" else {}
 
 
-def golden_parity(gpu_out, n, B, recipe="A"):
+def golden_parity(gpu_out, n, B, recipe="A", config=2, m=None):
     """The first pairs of the workload ARE a fixture produced by the real reference (tools/make_golden.py, weights seed 0, pair
-    seeds 1, 2, ...): recipe A -> nonadaptive_1024_b4 (4 pairs), recipe D -> trained_stats_1024_b8 (8 pairs)."""
+    seeds 1, 2, ...): recipe A -> nonadaptive_1024_b4 (4 pairs), recipe D -> trained_stats_1024_b8 (8 pairs).  Only cfg #2's semantics (256-d,
+    non-adaptive, weight seed 0, N = M = 1024, recipe A or D) ARE that fixture: any other --config / --kpts / --recipe returns None."""
     name, pairs = ("trained_stats_1024_b8", 8) if recipe == "D" else ("nonadaptive_1024_b4", 4)
     path = ROOT / "tests" / "golden" / f"{name}.npz"
-    if n != 1024 or B < pairs or not path.exists():
+    cfg = CONFIGS[config]
+    if config != 2 or cfg["dim"] != 256 or cfg["adaptive"] or cfg["wseed"] != 0 or recipe not in ("A", "D") or n != 1024 or (m is not None and m != 1024) or B < pairs or not path.exists():
         return None
     z = np.load(path, allow_pickle=False)
     refs = [{k: z[k][b] for k in ("matches0", "matches1", "matching_scores0", "matching_scores1")} for b in range(pairs)]
@@ -469,7 +471,7 @@ def main():
         dt = float(t.item())
         # what the collective looked like from inside the job (SCALE_r*.json then shows that RCCL saw N ranks): the result gather of
         # one step timed ALONE with events on this rank's stream (in the timed loop it runs on a side stream under the next forward)
-        width = 2 * n + 2 * m + 1
+        width = 3 * n + 3 * m + 2   # LG_WIRE_WIDTH: matches0 | scores0 | matches1 | scores1 | stop | status | prune0 | prune1
         send = torch.zeros((B, width), dtype=torch.int32, device=dev)
         recv = torch.empty((B * world, width), dtype=torch.int32, device=dev)
         via_host = dist.get_backend() == "gloo"
@@ -488,9 +490,10 @@ def main():
         seen = [None] * world
         dist.all_gather_object(seen, {"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(dev)})
         rccl = {"world": dist.get_world_size(), "backend": dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else " (debug backend, host copies)"),
-                "ranks_seen": seen, "gather": "all_gather_into_tensor of one packed int32 buffer [pairs, 2n + 2m + 1] per step (matches0 | scores0 bits | matches1 | scores1 bits | stop)",
+                "ranks_seen": seen, "gather": "all_gather_into_tensor of one packed int32 buffer [pairs, 3n + 3m + 2] per step (matches0 | scores0 bits | matches1 | scores1 bits | stop | status | prune0 | prune1): every rank rebuilds the full output dict of forward() from it",
                 "gather_bytes_sent_per_rank": int(send.numel() * 4), "gather_bytes_received_per_rank": int(recv.numel() * 4),
-                "gather_ms_alone": e0.elapsed_time(e1) / 20, "gather_overlap": "issued on a side stream behind an event; step i's gather runs under step i+1's forward"}
+                "gather_ms_alone": e0.elapsed_time(e1) / 20, "gather_overlap": "gather, unpack kernel and the copy of the [3][B] host block run on a side stream behind an event, under step i+1's forward",
+                "step_output_note": "the N > 1 step returns the same dict as the N = 1 step (see step_output): every rank rebuilds it for the WHOLE batch from the gathered rows"}
     elif not args.no_pipeline:
         # the reference's forward() is synchronous; the headline loop defers each step's host sync by one step.  The same K
         # steps once more with a synchronous forward per step, reported beside it
@@ -527,7 +530,7 @@ def main():
             g_ms = (time.perf_counter() - tg) / args.steps * 1e3
             same = bool(torch.equal(g_out["matches0"], out["matches0"])) if "matches0" in out else None
             gather_probe = {"ms_per_step_with_world1_gather": g_ms, "ms_per_step_plain": dt / args.steps * 1e3, "delta_ms": g_ms - dt / args.steps * 1e3,
-                            "gather_bytes": int(B * (2 * n + 2 * m + 1) * 4), "matches_equal_plain_loop": same,
+                            "gather_bytes": int(B * (3 * n + 3 * m + 2) * 4), "matches_equal_plain_loop": same,
                             "what": "K steps through PairShardedMatcher(always_gather) in a world of one over RCCL: engine-packed wire rows, all_gather_into_tensor on a side stream under the next forward, lg_unpack_wire"}
             dist.destroy_process_group()
         except Exception as exc:   # the probe must never cost the bench line
@@ -629,11 +632,15 @@ def main():
             "value_synchronous_forward": sync_value,   # pairs/s with model(data) per step (host sync inside every forward), N = 1 only
             "rccl": rccl,
             "gather_probe_one_gpu": gather_probe,
+            # what one step hands back: the same dict at every N — LightGlue.forward's keys / dtypes (ref :619-629), built inside the timed
+            # region with ONE deferred host synchronisation per step (N = 1: forward_deferred; N > 1: PairShardedMatcher.issue_local -> Pending.wait)
+            "step_output": {k: (str(v.dtype).replace("torch.", "") if torch.is_tensor(v) else f"list[{len(v)}] of {str(v[0].dtype).replace('torch.', '')}" if isinstance(v, list) and v else type(v).__name__)
+                            for k, v in sorted((out or {}).items())},
         }
         # match-index parity of the batch that was just timed (rank 0's pairs): against the reference's own fixture for the
         # first 4 pairs and against the oracle on the pairs the CPU leg runs anyway
         default_weights = args.precision in ("f16x3", "fp32")
-        res["parity"] = golden_parity(out, n, B, args.recipe) if default_weights else None
+        res["parity"] = golden_parity(out, n, B, args.recipe, args.config, m) if default_weights else None
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"], res["parity_oracle"] = cpu_baseline(sd, n, m, gpu_out=out, recipe=args.recipe, conf_kw={k: v for k, v in conf_kw.items() if k != "input_dim"}, dim=dim)
         json_out.write(json.dumps(res) + "\n")

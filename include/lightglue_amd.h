@@ -41,6 +41,20 @@ enum {
                               (|x| >= 65504, inf or NaN: the input domain of LG_PREC_F16X3 / _F16 / _BF16); its scores are not to be trusted */
 #define LG_ERR_DEVICE 5    /* an internal device-side wait expired (adaptive compaction): results of this forward are invalid */
 
+/* Envelope of one lg_engine_forward / lg_engine_reserve call (round 6).  Inside it every index of every kernel fits the integer type it is
+ * computed in, and the largest shapes are covered by GPU tests (N = M = 8192, B = 1; N = M = 4096, B = 32); a call outside it returns
+ * LG_ERR_INVALID with a message instead of writing past 32-bit offsets.  Split larger batches across calls (pairs are independent).
+ *   keypoints per image                  n0, n1 <= LG_MAX_KEYPOINTS
+ *   rows of one forward                  B * (cap0 + cap1) <= LG_MAX_ROWS          (cap = n rounded up to 128; X is then <= 2 GiB)
+ *   similarity-matrix elements           B * cap0 * cap1  <= LG_MAX_SIM_ELEMS
+ * Input domain of the score bar (|d score| <= 1e-3 against the fp32 reference, LG_PREC_F16X3): descriptors of norm <= ~30 (unit-norm extractor
+ * output times up to 10 x the recipes' norm spread of [0.5, 3]); beyond that the network's own fp32 evaluation differs by more than the bar
+ * (DESIGN.md section 1).  Values that leave the f16 operand range are reported per pair as LG_ERR_RANGE when LG_FLAG_CHECK_FINITE is set. */
+#define LG_WIRE_WIDTH(n0, n1) (3LL * (n0) + 3LL * (n1) + 2)   /* elements of one lg_forward_io.wire row */
+#define LG_MAX_KEYPOINTS 8192
+#define LG_MAX_ROWS 2097152            /* 2^21 */
+#define LG_MAX_SIM_ELEMS 2147483647LL  /* 2^31 - 1 */
+
 /* Mirrors LightGlue.default_conf (lightglue.py:322-335) for the keys the forward path reads. */
 typedef struct lg_config {
     int32_t input_dim;          /* 256 SuperPoint, 128 DISK/ALIKED/SIFT (lightglue.py:351-374)   */
@@ -105,8 +119,10 @@ typedef struct lg_forward_io {
     float *prune0_f32, *prune1_f32;        /* pruning disabled: n_layers for live rows (lightglue.py:616-617), 0 for the
                                               padding rows of a ragged batch                                          */
     /* One packed int32 row per pair, the wire format of the pair-sharded multi-GPU path (lightglue_amd/parallel.py, DESIGN.md
-     * section 6): [matches0 (n0) | scores0 bit patterns (n0) | matches1 (n1) | scores1 bit patterns (n1) | stop], row stride
-     * wire_stride >= 2 n0 + 2 n1 + 1 elements.  lg_unpack_wire() is the inverse on the receiving side. */
+     * section 6) — everything the reference's output dict holds for the pair, so that every rank can rebuild the SAME dict for the whole batch:
+     *   [matches0 (n0) | scores0 bit patterns (n0) | matches1 (n1) | scores1 bit patterns (n1) | stop | status | prune0 (n0) | prune1 (n1)]
+     * prune0/1 are the int32 counters when this forward prunes, else the bit patterns of the reference's float fill (n_layers, lightglue.py:616-617; 0 on
+     * the padding rows of a ragged batch).  Row stride wire_stride >= LG_WIRE_WIDTH(n0, n1) elements.  lg_unpack_wire() is the inverse on the receiving side. */
     int32_t *wire; int64_t wire_stride;
     int32_t *status;                       /* [B] LG_OK / LG_ERR_RANGE / LG_ERR_DEVICE per pair                       */
 } lg_forward_io;
@@ -135,11 +151,23 @@ int lg_engine_reserve(lg_engine* e, int32_t max_batch, int32_t max_n0, int32_t m
  * Asynchronous: no host synchronisation when the workspace is already large enough. */
 int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream);
 
-/* Inverse of lg_forward_io.wire on gathered rows (stateless; device pointers; replaces the slice / widen / index_select chain of
- * an all-gather consumer): row r of `wire` (stride wire_stride) goes to output pair order[r] (NULL = r; negative = skip the row); int64 indices and stop,
- * fp32 scores — the dtypes of the reference's output dict. */
-int lg_unpack_wire(const int32_t* wire, int64_t wire_stride, int32_t pairs, int32_t n0, int32_t n1, const int32_t* order,
-                   int64_t* matches0, float* scores0, int64_t* matches1, float* scores1, int64_t* stop, void* hip_stream);
+/* Inverse of lg_forward_io.wire on gathered rows (stateless; device pointers; ONE kernel; replaces the slice / widen / index_select chain and the per-pair
+ * torch.where of an all-gather consumer): row r of `wire` goes to output pair order[r] (NULL = r; negative = skip the row: the padding rows of a short shard).
+ * Writes the reference's output dtypes (lightglue.py:604-629): int64 indices / stop, fp32 scores, prune0/1 as int64 counters (with_prune) or as the float fill,
+ * the sorted match list of lightglue.py:593-602 per pair ([pairs_out][kmax][2] int64 + [pairs_out][kmax] scores, kmax = min(n0, n1)) — and `info`,
+ * [3][pairs_out] int32 = stop | number of matches | status per OUTPUT pair: the one small block a caller copies to the host (list lengths, B = 1's int stop, and
+ * the status every rank must raise on).  Any output pointer may be NULL. */
+typedef struct lg_unpack_io {
+    const int32_t *wire; int64_t wire_stride; int32_t rows;   /* gathered rows                                           */
+    int32_t n0, n1, with_prune, pairs_out;                    /* pairs_out: leading extent of the outputs / of info's rows */
+    const int32_t *order;                                     /* [rows] destination pair, or NULL                        */
+    int64_t *matches0, *matches1, *stop;                      /* [pairs_out][n0], [pairs_out][n1], [pairs_out]            */
+    float *scores0, *scores1;
+    int64_t *prune0_i64, *prune1_i64; float *prune0_f32, *prune1_f32;   /* with_prune: the i64 pair, else the f32 pair    */
+    int64_t *matches; float *match_scores;                    /* [pairs_out][kmax][2], [pairs_out][kmax]                 */
+    int32_t *info;                                            /* [3][pairs_out]: stop, n_matches, status                 */
+} lg_unpack_io;
+int lg_unpack_wire(const lg_unpack_io* io, void* hip_stream);
 
 /* Engine options (defaults are the product configuration; the others exist for tests, A/B measurements and profiling):
  *   "fused_tail"   1  out_proj + ffn + LayerNorm + GELU + residual as one kernel (lg_tail.hip); 0 = per-op GEMM kernels

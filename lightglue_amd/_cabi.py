@@ -56,6 +56,25 @@ class LgForwardIO(C.Structure):
     ]
 
 
+class LgUnpackIO(C.Structure):
+    """lg_unpack_io (include/lightglue_amd.h): the receiving side of the pair-sharded wire row"""
+    _fields_ = [
+        ("wire", _fp), ("wire_stride", C.c_int64), ("rows", C.c_int32),
+        ("n0", C.c_int32), ("n1", C.c_int32), ("with_prune", C.c_int32), ("pairs_out", C.c_int32),
+        ("order", _fp),
+        ("matches0", _fp), ("matches1", _fp), ("stop", _fp),
+        ("scores0", _fp), ("scores1", _fp),
+        ("prune0_i64", _fp), ("prune1_i64", _fp), ("prune0_f32", _fp), ("prune1_f32", _fp),
+        ("matches", _fp), ("match_scores", _fp),
+        ("info", _fp),
+    ]
+
+
+def wire_width(n0: int, n1: int) -> int:
+    """LG_WIRE_WIDTH: int32 elements of one lg_forward_io.wire row"""
+    return 3 * n0 + 3 * n1 + 2
+
+
 class LightGlueAmdError(RuntimeError):
     pass
 
@@ -86,7 +105,7 @@ def load() -> C.CDLL:
     lib.lg_engine_finalize_weights.argtypes = [C.c_void_p]
     lib.lg_engine_reserve.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.lg_engine_forward.argtypes = [C.c_void_p, C.POINTER(LgForwardIO), C.c_void_p]
-    lib.lg_unpack_wire.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7
+    lib.lg_unpack_wire.argtypes = [C.POINTER(LgUnpackIO), C.c_void_p]
     lib.lg_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
     lib.lg_engine_debug_stop_after.argtypes = [C.c_void_p, C.c_int32]
     lib.lg_engine_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]

@@ -239,7 +239,7 @@ struct OutArgs {
     const int* prune0; const int* prune1; const int* num0; const int* num1;
     long long* m0_64; long long* m1_64; long long* matches_64; long long* stop_64; long long* prune0_64; long long* prune1_64;
     float* prune0_f; float* prune1_f;
-    int* wire; long long wire_stride;
+    int* wire; long long wire_stride; int wire_prune;   // wire_prune: the row's prune block carries the int counters (else the float fill's bits)
     int* status; const int* range_flag; const int* device_err;
 };
 __global__ __launch_bounds__(256) void write_outputs_kernel(OutArgs a) {
@@ -247,43 +247,89 @@ __global__ __launch_bounds__(256) void write_outputs_kernel(OutArgs a) {
     const int stop = a.final_layer ? a.final_layer[b] + 1 : a.stop_const;
     int* wrow = a.wire ? a.wire + (long long)b * a.wire_stride : nullptr;
     auto count = [](const int* num, int pair, int n) { int v = num ? num[pair] : n; return v < 0 ? 0 : (v > n ? n : v); };
+    const int wp = 2 * a.n0 + 2 * a.n1 + 2;   // first element of the wire row's prune block
     if (i == 0) {
+        const int status = (a.device_err && *a.device_err) ? LG_ERR_DEVICE : ((a.range_flag && a.range_flag[b]) ? LG_ERR_RANGE : LG_OK);
         a.stop[b] = stop;
         if (a.stop_64) a.stop_64[b] = stop;
-        if (wrow) wrow[2 * a.n0 + 2 * a.n1] = stop;
-        if (a.status) a.status[b] = (a.device_err && *a.device_err) ? LG_ERR_DEVICE : ((a.range_flag && a.range_flag[b]) ? LG_ERR_RANGE : LG_OK);
+        if (wrow) { wrow[wp - 2] = stop; wrow[wp - 1] = status; }
+        if (a.status) a.status[b] = status;
     }
     if (i < a.n0) {
         const long long k = (long long)b * a.n0 + i;
         const int m = a.m0[k];
+        const float fill = i < count(a.num0, b, a.n0) ? (float)a.L : 0.f;
         if (a.m0_64) a.m0_64[k] = m;
         if (a.prune0_64) a.prune0_64[k] = a.prune0[k];
-        if (a.prune0_f) a.prune0_f[k] = i < count(a.num0, b, a.n0) ? (float)a.L : 0.f;
-        if (wrow) { wrow[i] = m; wrow[a.n0 + i] = __float_as_int(a.s0[k]); }
+        if (a.prune0_f) a.prune0_f[k] = fill;
+        if (wrow) { wrow[i] = m; wrow[a.n0 + i] = __float_as_int(a.s0[k]); wrow[wp + i] = a.wire_prune ? a.prune0[k] : __float_as_int(fill); }
     }
     if (i < a.n1) {
         const long long k = (long long)b * a.n1 + i;
         const int m = a.m1[k];
+        const float fill = i < count(a.num1, b, a.n1) ? (float)a.L : 0.f;
         if (a.m1_64) a.m1_64[k] = m;
         if (a.prune1_64) a.prune1_64[k] = a.prune1[k];
-        if (a.prune1_f) a.prune1_f[k] = i < count(a.num1, b, a.n1) ? (float)a.L : 0.f;
-        if (wrow) { wrow[2 * a.n0 + i] = m; wrow[2 * a.n0 + a.n1 + i] = __float_as_int(a.s1[k]); }
+        if (a.prune1_f) a.prune1_f[k] = fill;
+        if (wrow) { wrow[2 * a.n0 + i] = m; wrow[2 * a.n0 + a.n1 + i] = __float_as_int(a.s1[k]); wrow[wp + a.n0 + i] = a.wire_prune ? a.prune1[k] : __float_as_int(fill); }
     }
     if (a.matches_64 && i < 2 * a.kmax && (i >> 1) < a.n_matches[b]) {
         const long long k = (long long)b * a.kmax * 2 + i;
         a.matches_64[k] = a.matches[k];
     }
 }
-// inverse of the wire row on gathered rows (lg_unpack_wire).  grid (ceil(max(n0, n1, 1) / 256), pairs)
-__global__ __launch_bounds__(256) void unpack_wire_kernel(const int* wire, long long stride, int n0, int n1, const int* order,
-                                                           long long* m0, float* s0, long long* m1, float* s1, long long* stop) {
-    const int r = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    const int* row = wire + (long long)r * stride;
-    const long long d = order ? order[r] : r;
-    if (d < 0) return;                         // a padding row of a short shard
-    if (i < n0) { if (m0) m0[d * n0 + i] = row[i]; if (s0) s0[d * n0 + i] = __int_as_float(row[n0 + i]); }
-    if (i < n1) { if (m1) m1[d * n1 + i] = row[2 * n0 + i]; if (s1) s1[d * n1 + i] = __int_as_float(row[2 * n0 + n1 + i]); }
-    if (i == 0 && stop) stop[d] = row[2 * n0 + 2 * n1];
+// inverse of the wire row on gathered rows (lg_unpack_wire): one workgroup of 1024 threads per gathered row.  Besides the permutation / widening it
+// builds the reference's sorted match list (ref :593-602: indices of matches0 > -1 in ascending order, their partners, their scores) by ballot +
+// popcount prefix over the row, and the [3][pairs_out] host block (stop | n_matches | status).
+struct UnpackArgs {
+    const int* wire; long long stride; int n0, n1, with_prune, pairs_out, kmax; const int* order;
+    long long* m0; long long* m1; long long* stop; float* s0; float* s1;
+    long long* p0_64; long long* p1_64; float* p0_f; float* p1_f;
+    long long* matches; float* mscores; int* info;
+};
+__global__ __launch_bounds__(1024) void unpack_wire_kernel(UnpackArgs a) {
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n0 = a.n0, n1 = a.n1;
+    const int* row = a.wire + (long long)r * a.stride;
+    const long long d = a.order ? a.order[r] : r;
+    if (d < 0 || d >= a.pairs_out) return;      // a padding row of a short shard
+    const int wp = 2 * n0 + 2 * n1 + 2;
+    __shared__ int sh_cnt[16];
+    int base = 0;                                // matches found in the chunks before this one (the same value in every thread)
+    for (int i0 = 0; i0 < n0; i0 += 1024) {
+        const int i = i0 + tid;
+        int m = -1; float sc = 0.f;
+        if (i < n0) {
+            m = row[i]; sc = __int_as_float(row[n0 + i]);
+            if (a.m0) a.m0[d * n0 + i] = m;
+            if (a.s0) a.s0[d * n0 + i] = sc;
+            if (a.p0_64) a.p0_64[d * n0 + i] = row[wp + i];
+            if (a.p0_f) a.p0_f[d * n0 + i] = __int_as_float(row[wp + i]);
+        }
+        const bool valid = m > -1;
+        const unsigned long long bal = __ballot(valid);
+        if (lane == 0) sh_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        int before = base, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int c = sh_cnt[w]; if (w < wv) before += c; total += c; }
+        if (valid && a.matches) {
+            const long long k = d * a.kmax + before + __popcll(bal & ((1ull << lane) - 1ull));
+            a.matches[2 * k] = i; a.matches[2 * k + 1] = m;
+            if (a.mscores) a.mscores[k] = sc;
+        }
+        base += total;
+        __syncthreads();                         // sh_cnt is rewritten by the next chunk
+    }
+    for (int i = tid; i < n1; i += 1024) {
+        if (a.m1) a.m1[d * n1 + i] = row[2 * n0 + i];
+        if (a.s1) a.s1[d * n1 + i] = __int_as_float(row[2 * n0 + n1 + i]);
+        if (a.p1_64) a.p1_64[d * n1 + i] = row[wp + n0 + i];
+        if (a.p1_f) a.p1_f[d * n1 + i] = __int_as_float(row[wp + n0 + i]);
+    }
+    if (tid == 0) {
+        if (a.stop) a.stop[d] = row[wp - 2];
+        if (a.info) { a.info[d] = row[wp - 2]; a.info[a.pairs_out + d] = base; a.info[2 * a.pairs_out + d] = row[wp - 1]; }
+    }
 }
 
 int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
@@ -588,8 +634,23 @@ int lg_engine_finalize_weights(lg_engine* e) {
     return LG_OK;
 }
 
+// The envelope of include/lightglue_amd.h (LG_MAX_*): inside it every byte / element offset fits the type it is computed in (the raw-buffer
+// descriptors and 32-bit offsets of the compaction, lg_adaptive.hip, reach 4 GB; X is B * (cap0 + cap1) KB) — outside it the hardware would DROP
+// stores without an error, so the call is refused instead.
+static int check_envelope(long long B, long long n0, long long n1) {
+    const long long c0 = (n0 + 127) / 128 * 128, c1 = (n1 + 127) / 128 * 128;
+    if (n0 > LG_MAX_KEYPOINTS || n1 > LG_MAX_KEYPOINTS)
+        return fail(LG_ERR_INVALID, "more than LG_MAX_KEYPOINTS (8192) keypoints in one image");
+    if (B * (c0 + c1) > LG_MAX_ROWS)
+        return fail(LG_ERR_INVALID, "batch * (cap0 + cap1) exceeds LG_MAX_ROWS (2^21 keypoint rows per forward): split the batch across calls");
+    if (B * c0 * c1 > LG_MAX_SIM_ELEMS)
+        return fail(LG_ERR_INVALID, "batch * cap0 * cap1 exceeds LG_MAX_SIM_ELEMS (2^31 - 1 similarity entries per forward): split the batch across calls");
+    return LG_OK;
+}
+
 int lg_engine_reserve(lg_engine* e, int32_t max_batch, int32_t max_n0, int32_t max_n1) {
     if (!e || max_batch < 1 || max_n0 < 0 || max_n1 < 0) return fail(LG_ERR_INVALID, "bad argument");
+    TRY(check_envelope(max_batch, max_n0, max_n1));
     return ensure_workspace(e, max_batch, max_n0, max_n1);
 }
 
@@ -767,6 +828,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
     if (!e->weights_ready) return fail(LG_ERR_STATE, "weights not finalised");
     const int B = io->batch, n0 = io->n0, n1 = io->n1, L = e->cfg.n_layers, D = 256;
     if (B < 1 || n0 < 0 || n1 < 0) return fail(LG_ERR_INVALID, "bad batch / keypoint counts");
+    TRY(check_envelope(B, n0, n1));
     if (!io->stop || !io->n_matches) return fail(LG_ERR_INVALID, "null output pointer");
     if ((n0 && (!io->matches0 || !io->scores0)) || (n1 && (!io->matches1 || !io->scores1))) return fail(LG_ERR_INVALID, "null output pointer");
     if (n0 && n1 && (!io->matches || !io->match_scores)) return fail(LG_ERR_INVALID, "null match-list pointer");
@@ -780,7 +842,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
     const bool ext = (io->flags & LG_FLAG_EXT) != 0;            // round-5 extension fields present
     const bool check_finite = ext && (io->flags & LG_FLAG_CHECK_FINITE) != 0;
     if ((io->flags & LG_FLAG_CHECK_FINITE) && (!ext || !io->status)) return fail(LG_ERR_INVALID, "LG_FLAG_CHECK_FINITE needs LG_FLAG_EXT and a status array");
-    if (ext && io->wire && io->wire_stride < 2LL * n0 + 2LL * n1 + 1) return fail(LG_ERR_INVALID, "wire_stride < 2 n0 + 2 n1 + 1");
+    if (ext && io->wire && io->wire_stride < LG_WIRE_WIDTH(n0, n1)) return fail(LG_ERR_INVALID, "wire_stride < LG_WIRE_WIDTH(n0, n1) = 3 n0 + 3 n1 + 2");
     if (ext && do_prune && ((io->prune0_f32 || io->prune1_f32))) return fail(LG_ERR_INVALID, "prune0_f32 / prune1_f32 are the outputs of a forward WITHOUT pruning");
     if (ext && !do_prune && ((io->prune0_i64 || io->prune1_i64))) return fail(LG_ERR_INVALID, "prune0_i64 / prune1_i64 are the outputs of a forward WITH pruning");
     auto write_outputs = [&](const int* final_layer, int stop_const, const int* range_flag, const int* device_err) -> hipError_t {
@@ -791,7 +853,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
         if (ext) {
             o.m0_64 = (long long*)io->matches0_i64; o.m1_64 = (long long*)io->matches1_i64; o.matches_64 = (long long*)io->matches_i64; o.stop_64 = (long long*)io->stop_i64;
             o.prune0_64 = (long long*)io->prune0_i64; o.prune1_64 = (long long*)io->prune1_i64; o.prune0_f = io->prune0_f32; o.prune1_f = io->prune1_f32;
-            o.wire = io->wire; o.wire_stride = io->wire_stride; o.status = io->status; o.range_flag = range_flag; o.device_err = device_err;
+            o.wire = io->wire; o.wire_stride = io->wire_stride; o.wire_prune = do_prune ? 1 : 0; o.status = io->status; o.range_flag = range_flag; o.device_err = device_err;
         }
         int span = n0 > n1 ? n0 : n1; if (2 * max_matches > span) span = 2 * max_matches; if (span < 1) span = 1;
         hipLaunchKernelGGL(write_outputs_kernel, dim3((span + 255) / 256, B), dim3(256), 0, s, o);
@@ -1054,13 +1116,19 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
     return LG_OK;
 }
 
-int lg_unpack_wire(const int32_t* wire, int64_t wire_stride, int32_t pairs, int32_t n0, int32_t n1, const int32_t* order,
-                   int64_t* matches0, float* scores0, int64_t* matches1, float* scores1, int64_t* stop, void* hip_stream) {
-    if (!wire || pairs < 0 || n0 < 0 || n1 < 0 || wire_stride < 2LL * n0 + 2LL * n1 + 1) return fail(LG_ERR_INVALID, "lg_unpack_wire: bad argument");
-    if (pairs == 0) return LG_OK;
-    int span = n0 > n1 ? n0 : n1; if (span < 1) span = 1;
-    hipLaunchKernelGGL(unpack_wire_kernel, dim3((span + 255) / 256, pairs), dim3(256), 0, static_cast<hipStream_t>(hip_stream), wire, (long long)wire_stride, n0, n1,
-                       order, (long long*)matches0, scores0, (long long*)matches1, scores1, (long long*)stop);
+int lg_unpack_wire(const lg_unpack_io* io, void* hip_stream) {
+    if (!io || io->rows < 0 || io->n0 < 0 || io->n1 < 0 || io->pairs_out < 0) return fail(LG_ERR_INVALID, "lg_unpack_wire: bad argument");
+    if (io->rows == 0 || io->pairs_out == 0) return LG_OK;    // an empty gather (world of one, empty batch) is a no-op
+    if (!io->wire || io->wire_stride < LG_WIRE_WIDTH(io->n0, io->n1)) return fail(LG_ERR_INVALID, "lg_unpack_wire: null wire or wire_stride < LG_WIRE_WIDTH(n0, n1)");
+    if (io->n0 > LG_MAX_KEYPOINTS || io->n1 > LG_MAX_KEYPOINTS) return fail(LG_ERR_INVALID, "lg_unpack_wire: more than LG_MAX_KEYPOINTS keypoints");
+    UnpackArgs a{};
+    a.wire = io->wire; a.stride = io->wire_stride; a.n0 = io->n0; a.n1 = io->n1; a.with_prune = io->with_prune; a.pairs_out = io->pairs_out;
+    a.kmax = io->n0 < io->n1 ? io->n0 : io->n1; a.order = io->order;
+    a.m0 = (long long*)io->matches0; a.m1 = (long long*)io->matches1; a.stop = (long long*)io->stop; a.s0 = io->scores0; a.s1 = io->scores1;
+    if (io->with_prune) { a.p0_64 = (long long*)io->prune0_i64; a.p1_64 = (long long*)io->prune1_i64; }
+    else { a.p0_f = io->prune0_f32; a.p1_f = io->prune1_f32; }
+    a.matches = (long long*)io->matches; a.mscores = io->match_scores; a.info = io->info;
+    hipLaunchKernelGGL(unpack_wire_kernel, dim3(io->rows), dim3(1024), 0, static_cast<hipStream_t>(hip_stream), a);
     HIPCHK(hipGetLastError());
     return LG_OK;
 }

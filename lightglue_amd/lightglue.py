@@ -170,8 +170,11 @@ class LightGlue(nn.Module):
         self.return_log_assignment = False
         # extension: range guard (include/lightglue_amd.h LG_FLAG_CHECK_FINITE).  The split-f16 arithmetic needs |x| < 65504 for the residual stream
         # and q / k / v (like the reference's own fp16 mode); with the guard on, a forward whose values leave that range raises instead of returning
-        # inf / NaN scores.  Off by default (one compare per value in the tail and projection epilogues).
-        self.check_finite = False
+        # inf / NaN scores.  "first" (default, round 6): on for the FIRST forward after the weights changed (load_state_dict, .to(), in-place edits) —
+        # a checkpoint / input scale that does not fit the operand range shows on the first batch —, off afterwards; True: every forward; False: never
+        # (one compare per value in the tail and projection epilogues: not measurable, LAB_NOTES round 5 call h).
+        self.check_finite = "first"
+        self._guard_pending = True
         self._engine = None  # (handle, device_index, config signature)
         self._weights_sig = None
         self._plist = None
@@ -291,6 +294,7 @@ class LightGlue(nn.Module):
         with torch.cuda.device(device):
             _cabi.check(lib.lg_engine_finalize_weights(handle))
         self._weights_sig = sig
+        self._guard_pending = True      # check_finite == "first": the next forward runs with the range guard
 
     def refresh_weights(self):
         """Force a re-pack + upload of the parameters at the next forward (needed after edits the version counters do
@@ -322,12 +326,18 @@ class LightGlue(nn.Module):
             _cabi.check(_cabi.load().lg_engine_reserve(h, batch, n0, n1))
 
     # ------------------------------------------------------------------ forward
+    def will_prune(self, m: int, n: int) -> bool:
+        """Whether a forward on [B, m] x [B, n] keypoints runs with point pruning (ref :529-531: width_confidence > 0 and not the static-length mode) —
+        i.e. whether prune0 / prune1 come back as int64 counters or as the float fill (ref :616-617)."""
+        do_compile = bool(self.static_lengths) and max(m, n) <= max(self.static_lengths)
+        return self.conf.width_confidence > 0 and not do_compile
+
     def forward_raw(self, data: dict, wire: Optional[torch.Tensor] = None) -> dict:
         """The forward without output widening, ragged lists or the host synchronisation: int32 `matches0/1` [B, M|N], fp32
         `matching_scores0/1`, int32 `stop` and `status` [B] — views of the engine's own output buffers, valid on the current stream.
-        `wire`: optional int32 [pairs >= B][>= 2M + 2N + 1] buffer; the engine's last kernel then also packs one row per pair,
-        [matches0 | score0 bits | matches1 | score1 bits | stop] — the send buffer of `PairShardedMatcher` (int32 is enough for
-        N <= 4096; `lg_unpack_wire` widens on the receiving side)."""
+        `wire`: optional int32 [pairs >= B][>= 3M + 3N + 2] buffer; the engine's last kernel then also packs one row per pair,
+        [matches0 | score0 bits | matches1 | score1 bits | stop | status | prune0 | prune1] — the send buffer of `PairShardedMatcher`
+        (`lg_unpack_wire` rebuilds the output dict's tensors on the receiving side)."""
         return self.forward(data, _raw=True if wire is None else wire)
 
     @staticmethod
@@ -404,8 +414,7 @@ class LightGlue(nn.Module):
         ragged = num0 is not None or num1 is not None
 
         do_early_stop = conf.depth_confidence > 0
-        do_compile = bool(self.static_lengths) and max(m, n) <= max(self.static_lengths)
-        do_point_pruning = conf.width_confidence > 0 and not do_compile
+        do_point_pruning = self.will_prune(m, n)
 
         # ---- outputs: ONE int32, ONE int64 and ONE fp32 allocation, carved into the tensors of the C ABI (16-byte aligned pieces).  The engine's
         # last kernel writes the reference's dtypes itself (int64 indices / stop / prune counters, float prune0/1 without pruning, ref :616-629;
@@ -438,7 +447,7 @@ class LightGlue(nn.Module):
                 prune0, prune1 = ipiece(lbuf, loff, lsz, 4, b, m), ipiece(lbuf, loff, lsz, 5, b, n)
             else:   # ref :616-617 (padding rows of a ragged batch: 0)
                 prune0, prune1 = ipiece(fbuf, foff, fsz, 3, b, m), ipiece(fbuf, foff, fsz, 4, b, n)
-        wire = _raw if torch.is_tensor(_raw) else None          # PairShardedMatcher: [pairs >= b][>= 2m + 2n + 1] int32 rows the engine packs itself
+        wire = _raw if torch.is_tensor(_raw) else None          # PairShardedMatcher: [pairs >= b][>= 3m + 3n + 2] int32 rows the engine packs itself
 
         log_assignment = None
         if self.return_log_assignment and m > 0 and n > 0:
@@ -446,7 +455,14 @@ class LightGlue(nn.Module):
         handle = self._get_engine(device)
         self._sync_weights(handle, device)
         ptr = lambda t: None if t is None or t.numel() == 0 else t.data_ptr()
-        flags = _cabi.LG_FLAG_EXT | (0 if do_point_pruning or conf.width_confidence <= 0 else _cabi.LG_FLAG_NO_PRUNING) | (_cabi.LG_FLAG_CHECK_FINITE if self.check_finite else 0)
+        guard = self.check_finite is True or (self.check_finite == "first" and self._guard_pending)
+        self._guard_pending = False
+        if wire is not None:   # the engine's last kernel writes b rows of 3m + 3n + 2 int32 into it: a short or mistyped buffer would be an out-of-bounds device write
+            if not (wire.dtype is torch.int32 and wire.device == device and wire.dim() == 2 and wire.shape[0] >= b
+                    and wire.shape[1] >= _cabi.wire_width(m, n) and (wire.shape[1] == 1 or wire.stride(1) == 1)):
+                raise ValueError(f"wire must be an int32 [>= {b}, >= {_cabi.wire_width(m, n)}] tensor on {device} with unit column stride, got "
+                                 f"{wire.dtype} {tuple(wire.shape)} stride {tuple(wire.stride())} on {wire.device}")
+        flags = _cabi.LG_FLAG_EXT | (0 if do_point_pruning or conf.width_confidence <= 0 else _cabi.LG_FLAG_NO_PRUNING) | (_cabi.LG_FLAG_CHECK_FINITE if guard else 0)
         io = _cabi.LgForwardIO(
             b, m, n, flags,
             ptr(k0), ptr(k1), ptr(desc0), ptr(desc1), ptr(size0), ptr(size1),
@@ -465,7 +481,8 @@ class LightGlue(nn.Module):
             torch.cuda.synchronize(device)
             return None
         if raw_mode:
-            return {"matches0": m0, "matches1": m1, "matching_scores0": ms0, "matching_scores1": ms1, "stop": stop_nm[0], "status": stop_nm[2]}
+            return {"matches0": m0, "matches1": m1, "matching_scores0": ms0, "matching_scores1": ms1, "stop": stop_nm[0], "status": stop_nm[2],
+                    "pruning": do_point_pruning}   # "pruning": the wire row's prune block holds int counters (else the float fill's bits)
         # ---- output assembly (ref :593-629): the engine has written every fixed-shape tensor; only the ragged lists need the host.
 
         def assemble(host):   # host = [[stop per pair], [matches per pair], [status per pair]]

@@ -123,7 +123,8 @@ class PairShardedMatcher:
         return hit
 
     def issue_local(self, local: dict, global_batch: int, shards: Optional[List[List[int]]] = None) -> "Pending":
-        """Match the local shard and put the result gather in flight; `Pending.wait()` returns the full-batch dict."""
+        """Match the local shard and put the result gather in flight; `Pending.wait()` returns the full-batch dict — the SAME dict `LightGlue.forward` returns
+        (ref lightglue.py:604-629: int64 matches0/1, scores, `stop`, the ragged `matches` / `scores` lists, prune0/1), on every rank."""
         m = local["image0"]["keypoints"].shape[1]
         n = local["image1"]["keypoints"].shape[1]
         world, rank = self.world, self.rank
@@ -133,56 +134,69 @@ class PairShardedMatcher:
         assert local["image0"]["keypoints"].shape[0] == nloc, "local shard size does not match the pair assignment"
         dev = local["image0"]["keypoints"].device
         raw = getattr(self.matcher, "forward_raw", None)
-        # ---- one row per pair, [pairs_max][2m + 2n + 1] int32: matches0 | bits(scores0) | matches1 | bits(scores1) | stop.  The HIP matcher's last
-        # kernel packs the rows itself (lg_forward_io.wire): no framework kernel between the forward and the collective.
+        # ---- one row per pair, [pairs_max][3m + 3n + 2] int32: matches0 | bits(scores0) | matches1 | bits(scores1) | stop | status | prune0 | prune1
+        # (include/lightglue_amd.h lg_forward_io.wire).  The HIP matcher's last kernel packs the rows itself: no framework kernel between the forward and
+        # the collective.  The prune block holds int counters when the matcher prunes, else the bit patterns of the reference's float fill; which of the two
+        # is a property of the matcher's configuration, identical on every rank (weights and conf are replicated).
         per_rank = (global_batch + world - 1) // world
-        width = 2 * m + 2 * n + 1
+        width = wire_width(m, n)
         buf = torch.empty((per_rank, width), dtype=torch.int32, device=dev)
         if nloc < per_rank:
             buf[nloc:].zero_()
+        will_prune = getattr(self.matcher, "will_prune", None)
+        with_prune = bool(will_prune(m, n)) if will_prune is not None else bool(getattr(self.matcher, "wire_prunes", False))
         if nloc > 0 and raw is not None and dev.type == "cuda":
-            raw(local, wire=buf)
+            assert bool(raw(local, wire=buf)["pruning"]) == with_prune
         elif nloc > 0:   # any other matcher with the dict contract (the CPU tests' stand-in): pack here
             out = self.matcher(local)
-            stop = out["stop"]
-            stop_t = torch.full((nloc,), int(stop), dtype=torch.int32, device=dev) if not torch.is_tensor(stop) else stop.to(dev, torch.int32).reshape(nloc)
-            as_i32 = lambda t: t if t.dtype is torch.int32 else t.to(torch.int32)
-            buf[:nloc, 0:m] = as_i32(out["matches0"])
-            buf[:nloc, m:2 * m] = out["matching_scores0"].to(torch.float32).contiguous().view(torch.int32)
-            buf[:nloc, 2 * m:2 * m + n] = as_i32(out["matches1"])
-            buf[:nloc, 2 * m + n:2 * m + 2 * n] = out["matching_scores1"].to(torch.float32).contiguous().view(torch.int32)
-            buf[:nloc, -1] = stop_t
+            _pack_rows(buf[:nloc], out, m, n)
+            with_prune = "prune0" in out and not out["prune0"].dtype.is_floating_point
         if world == 1 and not (self.always_gather and dist.is_initialized()):
-            return Pending(self, buf[:nloc], None, None, m, n)
+            outs, info, pairs = _unpack(buf[:nloc], None, nloc, m, n, with_prune)
+            if not buf.is_cuda:
+                return Pending(outs, info, pairs, None)
+            host = torch.empty((3, pairs), dtype=torch.int32, pin_memory=True)     # as LightGlue.forward_deferred: the sizes travel behind an event
+            host.copy_(info, non_blocking=True)
+            done = torch.cuda.Event(); done.record(torch.cuda.current_stream(dev))
+            return Pending(outs, host, pairs, done)
         # RCCL ("nccl") gathers device buffers directly; gloo (CPU tests, or a debugging run of several ranks
         # on one GPU) goes through host copies
         via_host = dist.get_backend(self.group) == "gloo" and buf.is_cuda
-        src, dest = self._row_source(shards, per_rank, global_batch, dev)
+        _, dest = self._row_source(shards, per_rank, global_batch, dev)
         if buf.is_cuda and not via_host:
+            # the gather, its unpack kernel and the copy of the [3][B] host block all run on the SIDE stream behind an event, so that the caller's next forward
+            # (already enqueued on the compute stream when wait() is called) never stands between the host and the sizes it waits for
             if self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
-            ready = torch.cuda.Event(); ready.record(torch.cuda.current_stream(dev))
+            cur = torch.cuda.current_stream(dev)
+            ready = torch.cuda.Event(); ready.record(cur)
             gathered = torch.empty((world * per_rank, width), dtype=torch.int32, device=dev)
+            outs, info = _alloc_outputs(global_batch, m, n, with_prune, dev)
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ready)
                 dist.all_gather_into_tensor(gathered, buf, group=self.group)
+                _unpack_cuda(gathered, dest, global_batch, m, n, with_prune, outs, info, self._side)
+                host = torch.empty((3, global_batch), dtype=torch.int32, pin_memory=True)
+                host.copy_(info, non_blocking=True)
                 done = torch.cuda.Event(); done.record(self._side)
-            buf.record_stream(self._side); gathered.record_stream(self._side)
-            return Pending(self, gathered, src, done, m, n, dest)
+            for t in (buf, gathered, info, *[v for v in outs.values() if torch.is_tensor(v)]):
+                t.record_stream(self._side)
+            return Pending(outs, host, global_batch, done)
         send = buf.cpu() if via_host else buf
         gathered = torch.empty((world * per_rank, width), dtype=torch.int32, device=send.device)
         dist.all_gather_into_tensor(gathered, send, group=self.group)
         if via_host:
             gathered = gathered.to(dev)
-        return Pending(self, gathered, src, None, m, n, dest)
+        return Pending(*_unpack(gathered, dest, global_batch, m, n, with_prune), None)
 
     def forward_local(self, local: dict, global_batch: int, shards: Optional[List[List[int]]] = None) -> Dict[str, torch.Tensor]:
         return self.issue_local(local, global_batch, shards).wait()
 
     @staticmethod
     def ragged(result: Dict[str, torch.Tensor]):
-        """Rebuild the reference's ragged `matches` / `scores` lists (ref lightglue.py:593-602) from the
-        gathered fixed-shape tensors."""
+        """The reference's ragged `matches` / `scores` lists (ref lightglue.py:593-602) from fixed-shape `matches0` / `matching_scores0`: B `torch.where`
+        calls, i.e. B host synchronisations on a GPU — what `Pending.wait()` avoids (its lists come from lg_unpack_wire's match list + ONE host copy);
+        kept as the independent restatement the tests compare those lists with."""
         matches, scores = [], []
         for k in range(result["matches0"].shape[0]):
             valid = result["matches0"][k] > -1
@@ -192,31 +206,106 @@ class PairShardedMatcher:
         return matches, scores
 
 
-class Pending:
-    """A result gather in flight.  `wait()` orders the current stream behind it and unpacks the full-batch tensors."""
+def wire_width(m: int, n: int) -> int:
+    """int32 elements of one wire row (LG_WIRE_WIDTH, include/lightglue_amd.h)"""
+    return 3 * m + 3 * n + 2
 
-    def __init__(self, owner: PairShardedMatcher, gathered: torch.Tensor, src, done, m: int, n: int, dest=None):
-        self.owner, self.gathered, self.src, self.done, self.m, self.n, self.dest = owner, gathered, src, done, m, n, dest
+
+def _pack_rows(rows: torch.Tensor, out: dict, m: int, n: int) -> None:
+    """Generic (framework-op) form of the wire row for matchers without `forward_raw`: same layout as the engine's write_outputs_kernel."""
+    k, dev = rows.shape[0], rows.device
+    stop = out["stop"]
+    stop_t = torch.full((k,), int(stop), dtype=torch.int32, device=dev) if not torch.is_tensor(stop) else stop.to(dev, torch.int32).reshape(k)
+    as_i32 = lambda t: t if t.dtype is torch.int32 else t.to(torch.int32)
+    bits = lambda t: t.to(torch.float32).contiguous().view(torch.int32)
+    rows[:, 0:m] = as_i32(out["matches0"]); rows[:, m:2 * m] = bits(out["matching_scores0"])
+    rows[:, 2 * m:2 * m + n] = as_i32(out["matches1"]); rows[:, 2 * m + n:2 * m + 2 * n] = bits(out["matching_scores1"])
+    wp = 2 * m + 2 * n + 2
+    rows[:, wp - 2] = stop_t
+    status = out.get("status")
+    rows[:, wp - 1] = 0 if status is None else as_i32(torch.as_tensor(status)).to(dev).reshape(k)
+    for key, lo, cnt in (("prune0", wp, m), ("prune1", wp + m, n)):
+        p = out.get(key)
+        if p is None:
+            rows[:, lo:lo + cnt] = 0
+        else:
+            rows[:, lo:lo + cnt] = bits(p) if p.dtype.is_floating_point else as_i32(p)
+
+
+def _alloc_outputs(pairs: int, m: int, n: int, with_prune: bool, dev):
+    new = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+    kmax = min(m, n)
+    pdt = torch.int64 if with_prune else torch.float32
+    outs = {"matches0": new((pairs, m), torch.int64), "matches1": new((pairs, n), torch.int64),
+            "matching_scores0": new((pairs, m), torch.float32), "matching_scores1": new((pairs, n), torch.float32),
+            "stop": new((pairs,), torch.int64), "prune0": new((pairs, m), pdt), "prune1": new((pairs, n), pdt),
+            "_mlist": new((pairs, kmax, 2), torch.int64), "_mscores": new((pairs, kmax), torch.float32)}
+    return outs, torch.zeros((3, pairs), dtype=torch.int32, device=dev)
+
+
+def _unpack_cuda(g: torch.Tensor, dest, pairs: int, m: int, n: int, with_prune: bool, outs: dict, info: torch.Tensor, stream) -> None:
+    """ONE engine kernel on `stream`: row permutation, int64 widening, score / fill bit patterns back to fp32, the sorted match list and the host block
+    (lg_unpack_wire, include/lightglue_amd.h)"""
+    import ctypes as C
+    from . import _cabi
+    ptr = lambda t: None if t is None or t.numel() == 0 else t.data_ptr()
+    io = _cabi.LgUnpackIO(ptr(g), g.stride(0) if g.dim() == 2 else 0, g.shape[0], m, n, int(with_prune), pairs, ptr(dest),
+                          ptr(outs["matches0"]), ptr(outs["matches1"]), ptr(outs["stop"]), ptr(outs["matching_scores0"]), ptr(outs["matching_scores1"]),
+                          ptr(outs["prune0"]) if with_prune else None, ptr(outs["prune1"]) if with_prune else None,
+                          None if with_prune else ptr(outs["prune0"]), None if with_prune else ptr(outs["prune1"]),
+                          ptr(outs["_mlist"]), ptr(outs["_mscores"]), ptr(info))
+    with torch.cuda.device(g.device):
+        _cabi.check(_cabi.load().lg_unpack_wire(C.byref(io), C.c_void_p(stream.cuda_stream)))
+
+
+def _unpack(g: torch.Tensor, dest, pairs: int, m: int, n: int, with_prune: bool):
+    """(outputs, [3][pairs] info block, pairs) of gathered rows `g` on the CURRENT stream / on the CPU."""
+    outs, info = _alloc_outputs(pairs, m, n, with_prune, g.device)
+    if g.is_cuda:
+        _unpack_cuda(g, dest, pairs, m, n, with_prune, outs, info, torch.cuda.current_stream(g.device))
+        return outs, info, pairs
+    # CPU (gloo tests): the same unpack with framework ops
+    if dest is not None:
+        keep = dest >= 0
+        g, d = g[keep], dest[keep].long()
+    else:
+        d = torch.arange(g.shape[0])
+    wp = 2 * m + 2 * n + 2
+    fl = lambda t: t.contiguous().view(torch.float32)
+    outs["matches0"][d] = g[:, 0:m].long(); outs["matching_scores0"][d] = fl(g[:, m:2 * m])
+    outs["matches1"][d] = g[:, 2 * m:2 * m + n].long(); outs["matching_scores1"][d] = fl(g[:, 2 * m + n:2 * m + 2 * n])
+    outs["stop"][d] = g[:, wp - 2].long()
+    outs["prune0"][d] = g[:, wp:wp + m].long() if with_prune else fl(g[:, wp:wp + m])
+    outs["prune1"][d] = g[:, wp + m:wp + m + n].long() if with_prune else fl(g[:, wp + m:wp + m + n])
+    info[0, d] = g[:, wp - 2]; info[2, d] = g[:, wp - 1]
+    for k in d.tolist():
+        valid = outs["matches0"][k] > -1
+        c = int(valid.sum())
+        outs["_mlist"][k, :c, 0] = torch.where(valid)[0]; outs["_mlist"][k, :c, 1] = outs["matches0"][k][valid]
+        outs["_mscores"][k, :c] = outs["matching_scores0"][k][valid]
+        info[1, k] = c
+    return outs, info, pairs
+
+
+class Pending:
+    """A result gather in flight.  `wait()` returns the full-batch output dict of `LightGlue.forward` (same keys, dtypes and list semantics) and raises — on
+    EVERY rank — if any pair of any rank carries a non-zero status (LG_ERR_RANGE / LG_ERR_DEVICE)."""
+
+    def __init__(self, outs: dict, info: torch.Tensor, pairs: int, done=None):
+        self.outs, self.info, self.pairs, self.done = outs, info, pairs, done
 
     def wait(self) -> Dict[str, torch.Tensor]:
-        if self.done is not None:
-            torch.cuda.current_stream(self.gathered.device).wait_event(self.done)
-        m, n, g = self.m, self.n, self.gathered
-        if g.is_cuda:   # ONE engine kernel: row permutation, int64 widening, score bit patterns back to fp32 (lg_unpack_wire, include/lightglue_amd.h)
-            import ctypes as C
-            from . import _cabi
-            rows = g.shape[0] if self.src is None else self.src.shape[0]
-            new = lambda shape, dt: torch.empty(shape, dtype=dt, device=g.device)
-            out = {"matches0": new((rows, m), torch.int64), "matches1": new((rows, n), torch.int64), "matching_scores0": new((rows, m), torch.float32),
-                   "matching_scores1": new((rows, n), torch.float32), "stop": new((rows,), torch.int64)}
-            ptr = lambda t: None if t is None or t.numel() == 0 else t.data_ptr()
-            with torch.cuda.device(g.device):
-                _cabi.check(_cabi.load().lg_unpack_wire(ptr(g), g.stride(0), g.shape[0], m, n, ptr(self.dest) if self.src is not None else None,
-                                                        ptr(out["matches0"]), ptr(out["matching_scores0"]), ptr(out["matches1"]), ptr(out["matching_scores1"]),
-                                                        ptr(out["stop"]), C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)))
-            return out
-        full = g if self.src is None else g.index_select(0, self.src)
-        return {"matches0": full[:, 0:m].long(), "matches1": full[:, 2 * m:2 * m + n].long(),
-                "matching_scores0": full[:, m:2 * m].contiguous().view(torch.float32),
-                "matching_scores1": full[:, 2 * m + n:2 * m + 2 * n].contiguous().view(torch.float32),
-                "stop": full[:, -1].long()}
+        outs = self.outs
+        if self.done is not None:   # side-stream path: the host waits for gather + unpack + the copy of the host block ONLY; the compute stream is ordered behind them
+            self.done.synchronize()
+            torch.cuda.current_stream(outs["matches0"].device).wait_event(self.done)
+        host = self.info.tolist()       # THE host synchronisation of the step (a no-op on the side-stream path: `info` is pinned host memory there)
+        from .lightglue import LightGlue
+        LightGlue._raise_on_status(host[2])
+        counts = host[1]
+        mlist, mscores = outs.pop("_mlist"), outs.pop("_mscores")
+        outs["matches"] = [row[:c] for row, c in zip(mlist.unbind(0), counts)]
+        outs["scores"] = [row[:c] for row, c in zip(mscores.unbind(0), counts)]
+        if self.pairs == 1:
+            outs["stop"] = int(host[0][0])
+        return outs

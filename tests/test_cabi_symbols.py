@@ -44,6 +44,31 @@ def test_struct_layouts_match_header():
         return out
     assert fields_of("lg_config") == [f[0] for f in _cabi.LgConfig._fields_]
     assert fields_of("lg_forward_io") == [f[0] for f in _cabi.LgForwardIO._fields_]
+    assert fields_of("lg_unpack_io") == [f[0] for f in _cabi.LgUnpackIO._fields_]
+    # the wire width of the Python side == LG_WIRE_WIDTH of the header
+    macro = re.search(r"#define LG_WIRE_WIDTH\(n0, n1\) (.*?)\s+/\*", HEADER).group(1)
+    assert eval(macro.replace("LL", ""), {"n0": 300, "n1": 77}) == _cabi.wire_width(300, 77)
+
+
+def test_envelope_is_refused_without_touching_a_gpu():
+    """LG_MAX_KEYPOINTS / LG_MAX_ROWS / LG_MAX_SIM_ELEMS (include/lightglue_amd.h): a call outside the envelope returns LG_ERR_INVALID with a message before any
+    allocation or launch (4.3 M rows must be an error, not silently dropped stores)."""
+    lib = _cabi.load()
+    limits = {k: int(re.search(r"#define %s (\d+)" % k, HEADER).group(1)) for k in ("LG_MAX_KEYPOINTS", "LG_MAX_ROWS", "LG_MAX_SIM_ELEMS")}
+    assert limits == {"LG_MAX_KEYPOINTS": 8192, "LG_MAX_ROWS": 2 ** 21, "LG_MAX_SIM_ELEMS": 2 ** 31 - 1}
+    h = ctypes.c_void_p()
+    ok = _cabi.LgConfig(256, 256, 9, 4, 0, 0.95, 0.99, 0.1, -1, 4, -1)
+    assert lib.lg_engine_create(ctypes.byref(ok), ctypes.byref(h)) == _cabi.LG_OK
+    for (B, n0, n1, word) in ((1, 8193, 100, b"LG_MAX_KEYPOINTS"), (1050, 2048, 2048, b"LG_MAX_ROWS"), (129, 4096, 4096, b"LG_MAX_SIM_ELEMS"), (513, 2048, 2048, b"LG_MAX_ROWS")):
+        assert lib.lg_engine_reserve(h, B, n0, n1) == _cabi.LG_ERR_INVALID, (B, n0, n1)
+        assert word in lib.lg_last_error(), lib.lg_last_error()
+    lib.lg_engine_destroy(h)
+    # the receiving side of the wire: bad strides / counts are refused, an empty gather is a no-op
+    io = _cabi.LgUnpackIO()
+    io.rows, io.n0, io.n1, io.pairs_out = 0, 16, 16, 0
+    assert lib.lg_unpack_wire(ctypes.byref(io), None) == _cabi.LG_OK
+    io.rows, io.pairs_out, io.wire, io.wire_stride = 2, 2, 1 << 20, _cabi.wire_width(16, 16) - 1
+    assert lib.lg_unpack_wire(ctypes.byref(io), None) == _cabi.LG_ERR_INVALID
 
 
 def test_argument_validation_without_gpu():

@@ -91,12 +91,14 @@ def test_extension_outputs_equal_the_int32_ones(adaptive):
     model = gpu_util.make_model(sd, "f16x3", **kw)
     out = model(td)
     B, m, n = 3, 200, 168
-    wire = torch.full((B + 1, 2 * m + 2 * n + 5), -7, dtype=torch.int32, device="cuda")   # one spare row, four spare columns: must stay untouched
+    W = _cabi.wire_width(m, n)                                   # 3m + 3n + 2 (LG_WIRE_WIDTH)
+    wire = torch.full((B + 1, W + 4), -7, dtype=torch.int32, device="cuda")   # one spare row, four spare columns: must stay untouched
     raw = model.forward_raw(td, wire=wire)
     torch.cuda.synchronize()
     assert torch.equal(out["matches0"], raw["matches0"].long()) and torch.equal(out["matches1"], raw["matches1"].long())
     assert out["matches0"].dtype == torch.int64 and out["stop"].dtype == torch.int64
     assert torch.equal(out["stop"], raw["stop"].long())
+    assert raw["pruning"] == adaptive
     if adaptive:
         assert out["prune0"].dtype == torch.int64 and out["prune1"].dtype == torch.int64
         assert (out["prune0"][2] == 0).all() and (out["prune0"][1, 150:] == 0).all() and (out["prune0"][0] >= 1).all()
@@ -105,21 +107,47 @@ def test_extension_outputs_equal_the_int32_ones(adaptive):
         live0 = torch.arange(m, device="cuda")[None] < td["image0"]["num_keypoints"][:, None]
         assert torch.equal(out["prune0"], live0.float() * 9) and (out["prune1"][2, :100] == 9).all() and (out["prune1"][2, 100:] == 0).all()
     w = wire[:B].cpu()
-    assert (wire[B] == -7).all() and (wire[:B, 2 * m + 2 * n + 1:] == -7).all()
+    wp = 2 * m + 2 * n + 2
+    assert (wire[B] == -7).all() and (wire[:B, W:] == -7).all()
     assert torch.equal(w[:, :m], raw["matches0"].cpu()) and torch.equal(w[:, 2 * m:2 * m + n], raw["matches1"].cpu())
     assert torch.equal(w[:, m:2 * m].contiguous().view(torch.float32), raw["matching_scores0"].cpu())
     assert torch.equal(w[:, 2 * m + n:2 * m + 2 * n].contiguous().view(torch.float32), raw["matching_scores1"].cpu())
-    assert torch.equal(w[:, 2 * m + 2 * n], raw["stop"].cpu())
-    # lg_unpack_wire with a row permutation and a skipped row
+    assert torch.equal(w[:, wp - 2], raw["stop"].cpu()) and torch.equal(w[:, wp - 1], raw["status"].cpu())
+    if adaptive:
+        assert torch.equal(w[:, wp:wp + m].long(), out["prune0"].cpu()) and torch.equal(w[:, wp + m:wp + m + n].long(), out["prune1"].cpu())
+    else:
+        assert torch.equal(w[:, wp:wp + m].contiguous().view(torch.float32), out["prune0"].cpu())
+    # a wire buffer that is too narrow / of the wrong type is refused before the engine sees it
+    with pytest.raises(ValueError):
+        model.forward_raw(td, wire=torch.zeros((B, W - 1), dtype=torch.int32, device="cuda"))
+    with pytest.raises(ValueError):
+        model.forward_raw(td, wire=torch.zeros((B, W), dtype=torch.int64, device="cuda"))
+    # lg_unpack_wire with a row permutation and a skipped row: the reference's dtypes, the sorted match list, the host block
     order = torch.tensor([2, -1, 0, 1], dtype=torch.int32, device="cuda")
     rows = torch.cat([wire[2:3], wire[B:B + 1], wire[0:1], wire[1:2]]).contiguous()
     new = lambda shape, dt: torch.full(shape, -3, dtype=dt, device="cuda")
-    o = {"m0": new((B, m), torch.int64), "s0": new((B, m), torch.float32), "m1": new((B, n), torch.int64), "s1": new((B, n), torch.float32), "stop": new((B,), torch.int64)}
-    _cabi.check(_cabi.load().lg_unpack_wire(rows.data_ptr(), rows.stride(0), 4, m, n, order.data_ptr(), o["m0"].data_ptr(), o["s0"].data_ptr(),
-                                            o["m1"].data_ptr(), o["s1"].data_ptr(), o["stop"].data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    kmax = min(m, n)
+    pdt = torch.int64 if adaptive else torch.float32
+    o = {"m0": new((B, m), torch.int64), "s0": new((B, m), torch.float32), "m1": new((B, n), torch.int64), "s1": new((B, n), torch.float32), "stop": new((B,), torch.int64),
+         "p0": new((B, m), pdt), "p1": new((B, n), pdt), "ml": new((B, kmax, 2), torch.int64), "ms": new((B, kmax), torch.float32), "info": new((3, B), torch.int32)}
+    dp = lambda t: t.data_ptr()
+    io = _cabi.LgUnpackIO(dp(rows), rows.stride(0), 4, m, n, int(adaptive), B, dp(order), dp(o["m0"]), dp(o["m1"]), dp(o["stop"]), dp(o["s0"]), dp(o["s1"]),
+                          dp(o["p0"]) if adaptive else None, dp(o["p1"]) if adaptive else None, None if adaptive else dp(o["p0"]), None if adaptive else dp(o["p1"]),
+                          dp(o["ml"]), dp(o["ms"]), dp(o["info"]))
+    _cabi.check(_cabi.load().lg_unpack_wire(C.byref(io), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     assert torch.equal(o["m0"], out["matches0"]) and torch.equal(o["m1"], out["matches1"]) and torch.equal(o["stop"], out["stop"])
     assert torch.equal(o["s0"], out["matching_scores0"]) and torch.equal(o["s1"], out["matching_scores1"])
+    assert torch.equal(o["p0"], out["prune0"]) and torch.equal(o["p1"], out["prune1"])
+    info = o["info"].cpu()
+    assert torch.equal(info[0].long(), out["stop"].cpu()) and (info[2] == 0).all()
+    for b in range(B):
+        c = int(info[1, b])
+        assert c == out["matches"][b].shape[0]
+        assert torch.equal(o["ml"][b, :c], out["matches"][b]) and torch.equal(o["ms"][b, :c], out["scores"][b])
+    # an empty gather is a no-op, not an error
+    io0 = _cabi.LgUnpackIO(None, 0, 0, m, n, 0, 0, *([None] * 13))
+    _cabi.check(_cabi.load().lg_unpack_wire(C.byref(io0), None))
 
 
 def test_no_framework_kernels_between_engine_launches():

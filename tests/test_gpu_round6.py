@@ -1,0 +1,85 @@
+"""GPU tests of the round-6 additions: the call envelope (include/lightglue_amd.h LG_MAX_*), the range guard's new default ("first": on for the first forward after
+the weights changed), and the largest shape inside the envelope (N = M = 8192) against the pinned oracle, fixed depth and adaptive."""
+import numpy as np
+import pytest
+import torch
+
+import gpu_util
+from conftest import SCORE_TOL, assert_parity_with_explained_flips, require_gpu
+from lightglue_amd import _cabi
+from lightglue_amd import synthetic as synth
+from oracle import lightglue_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _empty_batch(B, n, m, dim=256):
+    e = lambda *shape: torch.empty(shape, device="cuda", dtype=torch.float32)
+    return {"image0": {"keypoints": e(B, n, 2), "descriptors": e(B, n, dim), "image_size": e(B, 2)},
+            "image1": {"keypoints": e(B, m, 2), "descriptors": e(B, m, dim), "image_size": e(B, 2)}}
+
+
+def test_calls_outside_the_envelope_are_refused():
+    """B * (cap0 + cap1) beyond 2^21 rows (the compaction's 32-bit byte offsets and 4 GB buffer descriptors) used to be silent corruption;
+    now the forward — and reserve — refuse it with a message, and the engine stays usable."""
+    require_gpu()
+    sd = synth.make_state_dict(0, recipe="C")
+    model = gpu_util.make_model(sd, "f16x3")
+    with pytest.raises(AssertionError, match="LG_MAX_ROWS"):
+        model(_empty_batch(1100, 1024, 1024))            # 1100 x 2048 = 2.25 M rows
+    with pytest.raises(AssertionError, match="LG_MAX_KEYPOINTS"):
+        model(_empty_batch(1, 8320, 64))
+    with pytest.raises(AssertionError, match="LG_MAX_SIM_ELEMS"):
+        model.reserve(129, 4096, 4096)
+    data = gpu_util.to_torch(synth.make_batch(3, 2, 200, 160))
+    out = model(data)
+    assert torch.isfinite(out["matching_scores0"]).all()
+
+
+def test_range_guard_is_on_for_the_first_forward_after_a_weight_change():
+    """check_finite == "first" (the default): an input scale / checkpoint that leaves the f16 operand range raises on the FIRST forward after load_state_dict
+    (and after any later weight change), costs nothing afterwards, and changes no output bit."""
+    require_gpu()
+    sd = synth.make_state_dict(0, recipe="A")
+    data = synth.make_batch(11, 2, 256, 192)
+    bad = {k: {kk: vv.copy() for kk, vv in v.items()} for k, v in data.items()}
+    bad["image0"]["descriptors"][1] *= np.float32(1e6)
+    model = gpu_util.make_model(sd, "f16x3", depth_confidence=-1, width_confidence=-1)
+    assert model.check_finite == "first"
+    with pytest.raises(_cabi.LightGlueAmdError, match="pair 1"):
+        model(gpu_util.to_torch(bad))
+    model(gpu_util.to_torch(bad))                          # second forward: guard off (the documented default), no raise
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    with pytest.raises(_cabi.LightGlueAmdError, match="pair 1"):
+        model(gpu_util.to_torch(bad))                      # armed again by the weight change
+    a = gpu_util.make_model(sd, "f16x3", depth_confidence=-1, width_confidence=-1)(gpu_util.to_torch(data))     # guarded forward
+    never = gpu_util.make_model(sd, "f16x3", depth_confidence=-1, width_confidence=-1)
+    never.check_finite = False
+    b = never(gpu_util.to_torch(data))
+    for k in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
+        assert torch.equal(a[k], b[k])
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_largest_shape_of_the_envelope_against_the_oracle(adaptive):
+    """N = M = 8192 (LG_MAX_KEYPOINTS), B = 1: scores within the bar of the pinned oracle, index flips explained; adaptive: recipe C with both images pruning
+    (64 chunks per segment through the in-place compaction), stop layer and prune counters identical."""
+    require_gpu()
+    torch.set_num_threads(8)
+    recipe = "C" if adaptive else "A"
+    sd = synth.make_state_dict(1, recipe=recipe)
+    data = synth.make_batch(91, 1, 8192, 8192)
+    conf_kw = dict() if adaptive else dict(depth_confidence=-1, width_confidence=-1)
+    ref = O.forward(sd, O.make_conf(**conf_kw), data, backend="torch")
+    model = gpu_util.make_model(sd, "f16x3", **conf_kw)
+    out = model(gpu_util.to_torch(data))
+    torch.cuda.synchronize()
+    gold = {k: np.asarray(ref[k]) for k in ("matches0", "matches1", "matching_scores0", "matching_scores1")}
+    case = {"conf": conf_kw, "recipe": recipe, "wseed": 1, "dseed": 91, "n": 8192, "m": 8192, "B": 1, "dim": 256}
+    flips = assert_parity_with_explained_flips(out, gold, case, sd, data, score_tol=SCORE_TOL)
+    assert sum(flips) <= 4, flips
+    assert int(out["stop"]) == int(np.asarray(ref["stop"]).reshape(-1)[0])
+    if adaptive:
+        assert (np.asarray(ref["prune0"]) < int(out["stop"])).any(), "the fixture must actually prune"
+        np.testing.assert_array_equal(out["prune0"].cpu().numpy(), np.asarray(ref["prune0"]))
+        np.testing.assert_array_equal(out["prune1"].cpu().numpy(), np.asarray(ref["prune1"]))

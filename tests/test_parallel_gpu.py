@@ -38,10 +38,17 @@ def _free_port():
 
 
 def _check(res, plain):
-    for k in KEYS:
-        assert torch.equal(res[k], plain[k]), k
-    stop = plain["stop"] if torch.is_tensor(plain["stop"]) else torch.full((res["stop"].shape[0],), int(plain["stop"]))
-    assert torch.equal(res["stop"].cpu(), stop.cpu().long())
+    """the sharded step returns the SAME product as LightGlue.forward: key set, dtypes, values, list semantics"""
+    assert set(res) == set(plain), set(res) ^ set(plain)
+    for k in KEYS + ("prune0", "prune1"):
+        assert res[k].dtype == plain[k].dtype and torch.equal(res[k], plain[k]), k
+    if torch.is_tensor(plain["stop"]):
+        assert res["stop"].dtype == plain["stop"].dtype and torch.equal(res["stop"], plain["stop"])
+    else:
+        assert isinstance(res["stop"], int) and res["stop"] == plain["stop"]
+    assert len(res["matches"]) == len(plain["matches"])
+    for a, b, c, d in zip(res["matches"], plain["matches"], res["scores"], plain["scores"]):
+        assert a.dtype == b.dtype and torch.equal(a, b) and c.dtype == d.dtype and torch.equal(c, d)
 
 
 @pytest.mark.parametrize("ragged", [False, True])
@@ -62,43 +69,102 @@ def test_world_of_one_over_rccl_equals_plain_forward(ragged):
         matches, scores = PairShardedMatcher.ragged(sharded(t))
         for b in range(5):
             assert torch.equal(matches[b], plain["matches"][b]) and torch.equal(scores[b], plain["scores"][b])
+        # adaptive depth / width: the prune counters and per-pair stop layers travel on the wire as well
+        amodel = gpu_util.make_model(synth.make_state_dict(0, recipe="C"), "f16x3", pruning_min_kpts=64)
+        aplain = amodel(t)
+        assert aplain["prune0"].dtype == torch.int64
+        _check(PairShardedMatcher(amodel)(t), aplain)
+        # B = 1: `stop` is a Python int, as in forward (ref :604)
+        one = {k: {kk: vv[:1] for kk, vv in v.items()} for k, v in t.items()}
+        _check(sharded(one), model(one))
     finally:
         dist.destroy_process_group()
 
 
-def _worker(rank, world, port, q, ragged):
+def test_status_of_a_poisoned_pair_raises_through_the_sharded_path():
+    """the range guard's per-pair status rides on the wire row; the sharded step must raise like forward does."""
+    require_gpu()
+    from lightglue_amd import _cabi
+    model = _model()
+    model.check_finite = True
+    t = _batch(False)
+    t["image0"]["descriptors"][3] *= 1e6
+    with pytest.raises(_cabi.LightGlueAmdError, match="pair 3"):
+        PairShardedMatcher(model)(t)
+
+
+def _worker(rank, world, port, q, ragged, poison=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        sharded = PairShardedMatcher(_model())
+        model = _model()
+        sharded = PairShardedMatcher(model)
         t = _batch(ragged)
-        if ragged:
+        if poison:
+            model.check_finite = True
+            t["image0"]["descriptors"][4] *= 1e6            # the last pair: the LAST rank's shard
+        if ragged and world == 2:
             assert sharded.assignment(t) != [[0, 1, 2], [3, 4]], "the balanced assignment must be non-contiguous for this test"
-        res = sharded(t)
-        q.put((rank, {k: v.cpu().numpy() for k, v in res.items()}))
+        try:
+            res = sharded(t)
+        except Exception as ex:
+            q.put((rank, {"error": f"{type(ex).__name__}: {ex}"}))
+            return
+        conv = lambda v: [x.cpu().numpy() for x in v] if isinstance(v, list) else (v.cpu().numpy() if torch.is_tensor(v) else v)
+        q.put((rank, {k: conv(v) for k, v in res.items()}))
     finally:
         dist.destroy_process_group()
+
+
+def _run(world, ragged, poison=False):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, ragged, poison)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return got
+
+
+def _check_np(got, plain):
+    assert set(got) == set(plain), set(got) ^ set(plain)
+    for k in KEYS + ("prune0", "prune1", "stop"):
+        np.testing.assert_array_equal(got[k], plain[k].cpu().numpy(), err_msg=k)
+        assert got[k].dtype == plain[k].cpu().numpy().dtype, k
+    for k in ("matches", "scores"):
+        assert len(got[k]) == len(plain[k])
+        for a, b in zip(got[k], plain[k]):
+            np.testing.assert_array_equal(a, b.cpu().numpy(), err_msg=k)
 
 
 @pytest.mark.parametrize("ragged", [False, True])
 def test_two_ranks_sharing_one_gpu_equal_plain_forward(ragged):
     require_gpu()
     plain = _model()(_batch(ragged))
-    port = _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, ragged)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = dict(q.get(timeout=600) for _ in range(2))
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    got = _run(2, ragged)
     for rank in (0, 1):
-        for k in KEYS:
-            np.testing.assert_array_equal(got[rank][k], plain[k].cpu().numpy(), err_msg=f"rank {rank} {k}")
-        np.testing.assert_array_equal(got[rank]["stop"], plain["stop"].cpu().numpy())
+        _check_np(got[rank], plain)
+
+
+def test_eight_ranks_sharing_one_gpu_equal_plain_forward():
+    """Rehearsal of the 8-rank job on one GPU over gloo (5 pairs on 8 ranks: three ranks hold an EMPTY shard and still take part in the gather)."""
+    require_gpu()
+    plain = _model()(_batch(False))
+    got = _run(8, False)
+    for rank in range(8):
+        _check_np(got[rank], plain)
+
+
+def test_a_poisoned_pair_on_the_last_rank_raises_on_rank_0():
+    require_gpu()
+    got = _run(2, False, poison=True)
+    for rank in (0, 1):
+        assert "error" in got[rank] and "pair 4" in got[rank]["error"] and "LG_ERR_RANGE" in got[rank]["error"], got[rank]
 
 
 def test_plain_bench_command_launches_its_own_ranks():

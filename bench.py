@@ -112,12 +112,12 @@ def flops_per_pair(n: int, m: int) -> float:
 
 # time ratio port / real reference, measured side by side in the build container (profiles/r03_cpu_reference.md,
 # tools/cpu_reference_table.py: 8 vCPU Intel Xeon @ 2.10 GHz, torch 2.10 CPU fp32, B = 1, pruning off; /root/reference loaded
-# standalone as tools/make_golden.py does).  The timed port is the oracle's restatement running on torch's CPU kernels
-# (oracle backend="torch": ATen linear / matmul / softmax / layer_norm / gelu and the fused fp32 SDPA the reference itself calls), so
-# it runs within 1.0-1.35x of the reference on the same cores (the plain numpy form: 1.2-1.5x at one thread, 4-5x at eight — numpy's
-# single-core softmax / erf / LayerNorm passes).  `cpu_baseline.reference_estimate_pairs_per_s` = value x this ratio.
+# standalone as tools/make_golden.py does; re-measured by oracle/cpu_leg.py whenever /root/reference is mounted).  The timed port is the
+# oracle's restatement running on torch's CPU kernels (oracle backend="torch": ATen linear / matmul / softmax / layer_norm / gelu and the
+# fused fp32 SDPA the reference itself calls), so it runs within 1.0-1.35x of the reference on the same cores.
+# `cpu_baseline.reference_estimate_pairs_per_s` = value x this ratio.
 PORT_OVER_REFERENCE_TIME = {"1 thread": {"N=512": 1.00, "N=1024": 1.02}, "8 threads": {"N=512": 1.10, "N=1024": 1.34}}
-REFERENCE_FILE = Path("/root/reference/lightglue/lightglue.py")
+CPU_LEG_THREADS = 16      # fixed: two whole L3 domains (CCDs) of one socket on the pool's EPYC 9575F hosts
 
 
 def _cpu_model():
@@ -130,138 +130,42 @@ def _cpu_model():
     return "unknown"
 
 
-def _time_reference(sd, n, threads, reps, warm=2):
-    """The unmodified reference module (CPU fp32, benchmark.py:18-43 methodology: warm-up, then timed repetitions of forward)."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("lg_ref", str(REFERENCE_FILE))
-    lg = importlib.util.module_from_spec(spec); spec.loader.exec_module(lg)
-    torch.set_grad_enabled(False)
-    model = lg.LightGlue(features=None, depth_confidence=-1, width_confidence=-1).eval()
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
-    data = synthetic.make_batch(1, 1, n, n)
-    td = {k: {kk: torch.from_numpy(vv) for kk, vv in v.items()} for k, v in data.items()}
-    old = torch.get_num_threads(); torch.set_num_threads(threads)
-    try:
-        for _ in range(warm):
-            model(td)
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            model(td)
-        return (time.perf_counter() - t0) / reps
-    finally:
-        torch.set_num_threads(old)
-
-
-def timed_port_forward(sd, conf, data, threads):
-    """One forward of the port (oracle/, torch-kernel backend) — the timed CPU leg and, with the same call, the checker of the GPU batch."""
-    from oracle import lightglue_oracle as O
-    return O.forward(sd, conf, data, backend="torch")
-
-
 def _port_over_reference(n, threads):
     """Measured time ratio port / reference for the nearest measured (N, threads) cell of profiles/r03_cpu_reference.md."""
     row = PORT_OVER_REFERENCE_TIME["1 thread" if threads <= 2 else "8 threads"]
     return row["N=512" if n <= 768 else "N=1024"]
 
 
-def cpu_baseline(sd, n, m, gpu_out=None, budget_s=24.0, max_pairs=32, recipe="A", conf_kw=None, dim=256):
-    """CPU leg (rank 0, N = 1 only; ~25-35 s in total).  The port of the reference's CPU fp32 path (oracle/, torch-kernel backend:
-    the same restatement on the ATen CPU kernels the reference computes with) is timed on pairs of the SAME seeded batch the GPU
-    matched (pair seeds 1, 2, ...), so the same calls also CHECK the GPU result (returned as the second value).
-    Method: the thread count is the fastest of 8 / 16 / 32 on one probe pair; the process is pinned to that many
-    distinct cores for the timed part; the same k pairs are timed THREE times and `value` is the median rate; the 1-thread rate is
-    reported beside it.  When /root/reference is mounted (build container) the real reference is timed too; on the GPU box it is not,
-    and the port's measured slowdown against the reference is reported instead."""
-    from oracle import lightglue_oracle as O  # test/baseline infrastructure only: the checker and the timed baseline
-
-    from contextlib import contextmanager
-
-    @contextmanager
-    def threadpool_limits(limits):   # intra-op threads of torch's CPU kernels (the timed port runs on them), pinned to `limits` cores
-        old = torch.get_num_threads()
-        aff = None
-        try:
-            aff = os.sched_getaffinity(0)
-            cores = sorted(aff)[:limits]          # logical CPUs i and i + ncpu / 2 are SMT siblings on the pool's EPYCs: the first ids are distinct cores
-            if len(cores) == limits:
-                os.sched_setaffinity(0, cores)
-        except (AttributeError, OSError):
-            aff = None
-        torch.set_num_threads(limits)
-        try:
-            yield
-        finally:
-            torch.set_num_threads(old)
-            if aff is not None:
-                try:
-                    os.sched_setaffinity(0, aff)
-                except OSError:
-                    pass
-
-    conf = O.make_conf(**(conf_kw if conf_kw is not None else dict(depth_confidence=-1, width_confidence=-1)))
-    kw = batch_kwargs(recipe)
-    ncpu = os.cpu_count() or 1
-    best, best_t = 1, float("inf")
-    probe = synthetic.make_batch(999, 1, n, m, dim, **kw)
-    for th in sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu)}):
-        with threadpool_limits(limits=th):
-            t = float("inf")
-            for _ in range(2):   # the first call at a new thread count also pays the pool's start-up
-                t0 = time.perf_counter(); timed_port_forward(sd, conf, probe, th); t = min(t, time.perf_counter() - t0)
-        if t < best_t:
-            best, best_t = th, t
-    # k pairs per round so that three rounds fit the budget; at least one
-    k = int(max(1, min(max_pairs, budget_s / 3.0 / max(best_t, 1e-3))))
-    batches = [synthetic.make_batch(1 + i, 1, n, m, dim, **kw) for i in range(k)]      # == pairs 0..k-1 of rank 0's GPU batch
-    rates, refs = [], []
-    with threadpool_limits(limits=best):
-        for rnd in range(3):
-            t0 = time.perf_counter()
-            out = [timed_port_forward(sd, conf, d, best) for d in batches]
-            rates.append(k / (time.perf_counter() - t0))
-            if rnd == 0:
-                refs = out
-    value = float(np.median(rates))
-    one_thread = None
-    if best_t * best < 25.0:   # (skipped for the big shapes: one thread would take minutes at N = 4096)
-        with threadpool_limits(limits=1):
-            t0 = time.perf_counter(); timed_port_forward(sd, conf, batches[0], 1); one_thread = 1.0 / (time.perf_counter() - t0)
-    # SURVEY §8d: cfg #1 (N=M=512, B=1, fp32, SuperPoint dim, non-adaptive) with 1 thread and with the chosen thread count
-    cfg1 = {}
-    if dim == 256:
-        conf1 = O.make_conf(depth_confidence=-1, width_confidence=-1)
-        d512 = synthetic.make_batch(1, 1, 512, 512)
-        for th in sorted({1, best}):
-            with threadpool_limits(limits=th):
-                timed_port_forward(sd, conf1, d512, th)
-                t1 = time.perf_counter(); timed_port_forward(sd, conf1, d512, th); timed_port_forward(sd, conf1, d512, th)
-                cfg1[f"{th} thread(s)"] = round(2.0 / (time.perf_counter() - t1), 3)
-    res = {"value": value, "unit": "image-pairs/s", "cores": best, "kind": "port",
-           "sample": f"{k} pair(s) N={n} M={m} of the benchmark's own batch timed 3 times (median), 9 layers, fp32 port of the reference CPU path (oracle/ on torch's CPU kernels), "
-                     f"{best} thread(s) pinned to {best} cores (fastest of 8/16/32 on {ncpu} logical cores)",
-           "rounds_pairs_per_s": [round(r, 3) for r in rates], "one_thread_pairs_per_s": None if one_thread is None else round(one_thread, 3),
-           "cpu_model": _cpu_model(), "logical_cores": ncpu,
-           "cfg1_n512_b1_pairs_per_s": cfg1,
-           "port_over_reference_time_ratio": PORT_OVER_REFERENCE_TIME,
-           "port_over_reference_source": "profiles/r03_cpu_reference.md (tools/cpu_reference_table.py: the unmodified reference and this port timed side by side in the build container)",
-           # what the REAL reference would do on these cores, by the measured ratio (the GPU box has no /root/reference)
-           "reference_estimate_pairs_per_s": round(value * _port_over_reference(n, best), 3),
-           # the ratio behind the estimate was measured at 1 and 8 threads on the build container's Xeon; here it is applied to `cores`
-           # threads of this box's CPU — outside the thread count and the CPU it was measured on (VERDICT r03 weak 9).  The port's own
-           # number (`value`) is the measured one
-           "reference_estimate_note": f"ratio measured at 1 / 8 threads on an 8-vCPU Xeon (build container), applied to {best} thread(s) of {_cpu_model()}: an extrapolation, not a measurement"}
-    nonadaptive = conf_kw is None or (conf_kw.get("depth_confidence", 1) <= 0 and conf_kw.get("width_confidence", 1) <= 0)
-    if REFERENCE_FILE.exists() and dim == 256 and n == m and nonadaptive:   # build container only: time the real thing beside the port
-        try:
-            ref_t = {f"N={kk} {th} thread(s)": round(1.0 / _time_reference(sd, kk, th, reps=3), 3) for kk in (512, n) for th in sorted({1, min(8, ncpu)})}
-            res["reference_pairs_per_s"] = ref_t
-            res["kind"] = "reference"
-            res["value"] = max(v for kk, v in ref_t.items() if kk.startswith(f"N={n} "))
-            res["cores"] = min(8, ncpu)
-            res["sample"] = f"unmodified reference (lightglue.py loaded standalone), CPU fp32, B=1, N=M={n}, 2 warm-up + 3 timed forwards; port timings kept in port_pairs_per_s"
-            res["port_pairs_per_s"] = value
-        except Exception as exc:  # pragma: no cover
-            res["reference_error"] = repr(exc)[:200]
+def cpu_baseline(sd, n, m, gpu_out=None, budget_s=20.0, max_pairs=32, recipe="A", conf_kw=None, dim=256, wseed=0):
+    """CPU leg (rank 0, N = 1 only; ~30 s in total) — run by oracle/cpu_leg.py IN ITS OWN PROCESS: affinity set before torch is imported (whole L3 domains of one
+    socket, one hardware thread per physical core, not CPU 0's domain), a FIXED thread count, the same k pairs timed five times (median + spread), cfg #1 (N = 512,
+    B = 1) at 1 and N threads beside it.  The port of the reference's CPU fp32 path (oracle/, torch-kernel backend) is timed on pairs of the SAME seeded batch the
+    GPU matched (pair seeds 1, 2, ...), so the same calls also CHECK the GPU result (returned as the second value).  `kind` is "port" on the GPU box: the reference
+    is a Python module, which may not travel there; where /root/reference is mounted (build container) the unmodified module is timed beside the port."""
+    import subprocess
+    import tempfile
+    conf = conf_kw if conf_kw is not None else dict(depth_confidence=-1, width_confidence=-1)
+    with tempfile.TemporaryDirectory() as tmp:
+        out_npz = os.path.join(tmp, "cpu_leg.npz")
+        cmd = [sys.executable, str(ROOT / "oracle" / "cpu_leg.py"), "--n", str(n), "--m", str(m), "--dim", str(dim), "--recipe", recipe, "--wseed", str(wseed),
+               "--conf", json.dumps(conf), "--threads", str(CPU_LEG_THREADS), "--budget", str(budget_s), "--max-pairs", str(max_pairs), "--out", out_npz]
+        env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        if p.returncode != 0:
+            return {"error": p.stderr[-500:], "kind": "port"}, None
+        res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        z = np.load(out_npz)
+        k = int(z["pairs"])
+        refs = [{key: z[f"{key}_{i}"] for key in ("matches0", "matches1", "matching_scores0", "matching_scores1")} for i in range(k)]
+    res.update({"cpu_model": _cpu_model(), "logical_cores": os.cpu_count(),
+                "port_over_reference_time_ratio": PORT_OVER_REFERENCE_TIME,
+                "port_over_reference_source": "profiles/r03_cpu_reference.md (tools/cpu_reference_table.py: the unmodified reference and this port timed side by side in the build container); "
+                                              "oracle/cpu_leg.py re-measures it wherever /root/reference is mounted (reference_pairs_per_s / port_pairs_per_s)"})
+    if res.get("kind") == "port":
+        # what the REAL reference would do on these cores, by the measured ratio (the GPU box has no /root/reference: a Python reference may not travel)
+        res["reference_estimate_pairs_per_s"] = round(res["value"] * _port_over_reference(n, res["cores"]), 3)
+        res["reference_estimate_note"] = (f"ratio measured at 1 / 8 threads on an 8-vCPU Xeon (build container), applied to {res['cores']} thread(s) of {_cpu_model()}: "
+                                          "an extrapolation, not a measurement")
     parity = None
     if gpu_out is not None:
         parity = parity_block(gpu_out, refs, n, m, source=f"oracle (port of the reference CPU path on torch CPU kernels, fp32) on pairs 0..{k - 1} of the timed batch")
@@ -642,7 +546,7 @@ def main():
         default_weights = args.precision in ("f16x3", "fp32")
         res["parity"] = golden_parity(out, n, B, args.recipe, args.config, m) if default_weights else None
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"], res["parity_oracle"] = cpu_baseline(sd, n, m, gpu_out=out, recipe=args.recipe, conf_kw={k: v for k, v in conf_kw.items() if k != "input_dim"}, dim=dim)
+            res["cpu_baseline"], res["parity_oracle"] = cpu_baseline(sd, n, m, gpu_out=out, recipe=args.recipe, conf_kw={k: v for k, v in conf_kw.items() if k != "input_dim"}, dim=dim, wseed=cfg["wseed"])
         json_out.write(json.dumps(res) + "\n")
         json_out.flush()
     if world > 1:

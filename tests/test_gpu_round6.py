@@ -83,3 +83,21 @@ def test_largest_shape_of_the_envelope_against_the_oracle(adaptive):
         assert (np.asarray(ref["prune0"]) < int(out["stop"])).any(), "the fixture must actually prune"
         np.testing.assert_array_equal(out["prune0"].cpu().numpy(), np.asarray(ref["prune0"]))
         np.testing.assert_array_equal(out["prune1"].cpu().numpy(), np.asarray(ref["prune1"]))
+
+
+def test_verify_pretrained_on_a_released_format_checkpoint(tmp_path):
+    """tools/verify_pretrained.py runs offline on a recipe-D checkpoint written with the released checkpoints' key names and reproduces the
+    committed reference fixture trained_stats_1024_b8 (inputs AND reference outputs replayed) — the one-command job for whoever holds the real weights."""
+    require_gpu()
+    import subprocess
+    import sys
+    from pathlib import Path
+    from test_tools import _legacy_checkpoint
+    root = Path(__file__).resolve().parents[1]
+    ck = _legacy_checkpoint(tmp_path / "recipeD_legacy.pth")
+    p = subprocess.run([sys.executable, str(root / "tools" / "verify_pretrained.py"), str(ck), "--sizes", "512", "--pairs", "1", "--fixture", "trained_stats_1024_b8"],
+                       capture_output=True, text=True, timeout=1500, cwd=str(root))
+    assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-2000:])
+    line = [ln for ln in p.stdout.splitlines() if "fixture trained_stats_1024_b8" in ln][0]
+    assert "| 0 / 0 |" in line and line.rstrip().endswith("| ok |"), line
+    assert "RESULT: inside the bar" in p.stdout

@@ -16,6 +16,28 @@ from lightglue_amd import synthetic  # noqa: E402
 from oracle import lightglue_oracle as O  # noqa: E402
 from threadpoolctl import threadpool_limits  # noqa: E402
 
+def _time_reference(sd, n, threads, reps, warm=2):
+    """The unmodified reference module (CPU fp32, /root/reference/benchmark.py:18-43's method: warm-up, then timed repetitions of forward)."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("lg_ref", "/root/reference/lightglue/lightglue.py")
+    lg = importlib.util.module_from_spec(spec); spec.loader.exec_module(lg)
+    torch.set_grad_enabled(False)
+    model = lg.LightGlue(features=None, depth_confidence=-1, width_confidence=-1).eval()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    td = {k: {kk: torch.from_numpy(vv) for kk, vv in v.items()} for k, v in synthetic.make_batch(1, 1, n, n).items()}
+    old = torch.get_num_threads(); torch.set_num_threads(threads)
+    try:
+        for _ in range(warm):
+            model(td)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            model(td)
+        return (time.perf_counter() - t0) / reps
+    finally:
+        torch.set_num_threads(old)
+
+
 sd = synthetic.make_state_dict(0, recipe="A")
 conf = O.make_conf(depth_confidence=-1, width_confidence=-1)
 import torch  # noqa: E402
@@ -30,7 +52,7 @@ print("|---|---|---|---|---|---|---|---|---|")
 ratios = {}
 for n in (512, 1024):
     for th in (1, 8):
-        tr = min(bench._time_reference(sd, n, th, reps=5) for _ in range(2))
+        tr = min(_time_reference(sd, n, th, reps=5) for _ in range(2))
         data = synthetic.make_batch(1, 1, n, n)
         with threadpool_limits(limits=th):
             O.forward(sd, conf, data)

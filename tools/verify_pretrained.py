@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Parity of the HIP engine on a REAL checkpoint — one command for whoever has the released weights (they are network-only; this repository's fixtures use
+calibrated stand-ins, recipes D / E).
+
+    python tools/verify_pretrained.py superpoint_lightglue.pth                      # synthetic keypoints / unit-norm descriptors at N = 512 / 1024 / 2048
+    python tools/verify_pretrained.py superpoint_lightglue.pth features.npz         # + your own extractor output
+    python tools/verify_pretrained.py ckpt.pth --reference ~/src/LightGlue          # where the reference repository is checked out (default: /root/reference,
+                                                                                    #   else the pinned oracle restatement stands in for it)
+    python tools/verify_pretrained.py ckpt.pth --fixture trained_stats_1024_b8      # replay a committed reference fixture with the checkpoint's weights
+
+What it does (ref lightglue.py:415-434 for the checkpoint format):
+  1. loads the checkpoint (released `self_attn.{i}.*` / `cross_attn.{i}.*` names or module-tree names) into the CPU fp32 side — the unmodified reference module
+     loaded standalone when it can be found, else oracle/lightglue_oracle.py — and into lightglue_amd.LightGlue (default precision f16x3);
+  2. runs both on the same inputs, pruning / early stop OFF and ON, and prints per case: index mismatches on both image sides, max / rms |d score| on equal
+     indices, stop layer and prune counters; the bar is 0 unexplained flips and |d score| <= 1e-3 (exit status 1 otherwise);
+  3. prints the checkpoint's per-layer statistics — median per-row attention logit spread (self / cross), residual rms — next to what recipes D / E were
+     calibrated to (spread 25, rms 3.5 -> 27), i.e. whether the precision design's stand-ins resemble this checkpoint;
+  4. prints the same parity for `attention_precision="fp16"` (the fast opt-in), so that its envelope on REAL weights is known.
+
+features.npz: keypoints0 [N,2], descriptors0 [N,D], keypoints1 [M,2], descriptors1 [M,D], optional image_size0 / image_size1 [2] (w, h), scales*/oris* for SIFT."""
+from __future__ import annotations
+
+import argparse
+import importlib.util
+import re
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+from lightglue_amd import LightGlue  # noqa: E402
+from lightglue_amd import synthetic as synth  # noqa: E402
+
+SCORE_TOL = 1e-3
+
+
+def load_checkpoint(path):
+    sd = torch.load(path, map_location="cpu")
+    if "state_dict" in sd and isinstance(sd["state_dict"], dict):
+        sd = sd["state_dict"]
+    legacy = any(re.match(r"(self|cross)_attn\.\d+\.", k) for k in sd)
+    n_layers = 1 + max(int(m.group(2)) for m in (re.match(r"(transformers|self_attn|cross_attn|log_assignment|token_confidence)\.(\d+)\.", k) for k in sd) if m)
+    sd = LightGlue.rename_legacy_keys(sd, n_layers)
+    sd = {k: v.float() for k, v in sd.items() if torch.is_tensor(v)}
+    input_dim = sd["input_proj.weight"].shape[1] if "input_proj.weight" in sd else 256
+    add_scale_ori = sd["posenc.Wr.weight"].shape[1] == 4
+    return sd, dict(n_layers=n_layers, input_dim=int(input_dim), add_scale_ori=bool(add_scale_ori)), legacy
+
+
+def find_reference(hint):
+    for cand in ([Path(hint)] if hint else []) + [Path("/root/reference")]:
+        f = cand / "lightglue" / "lightglue.py" if cand.is_dir() else cand
+        if f.exists():
+            spec = importlib.util.spec_from_file_location("lg_ref", str(f))
+            mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+            return mod, str(f)
+    return None, None
+
+
+def cpu_side(ref_mod, sd, arch, conf_kw, prune_th):
+    """callable(data numpy dict, B = 1 slices) -> output dict of numpy arrays, on CPU in fp32"""
+    if ref_mod is not None:
+        saved = dict(ref_mod.LightGlue.pruning_keypoint_thresholds)
+        model = ref_mod.LightGlue(features=None, **arch, **conf_kw).eval()
+        res = model.load_state_dict(sd, strict=False)
+        assert not res.unexpected_keys, res.unexpected_keys[:5]
+
+        def run(data):
+            for k in ref_mod.LightGlue.pruning_keypoint_thresholds:
+                ref_mod.LightGlue.pruning_keypoint_thresholds[k] = prune_th
+            try:
+                with torch.no_grad():
+                    o = model({k: {kk: torch.from_numpy(vv) for kk, vv in v.items()} for k, v in data.items()})
+            finally:
+                ref_mod.LightGlue.pruning_keypoint_thresholds.update(saved)
+            return {"matches0": o["matches0"][0].numpy(), "matches1": o["matches1"][0].numpy(), "matching_scores0": o["matching_scores0"][0].numpy(),
+                    "matching_scores1": o["matching_scores1"][0].numpy(), "stop": int(o["stop"]), "prune0": o["prune0"][0].numpy(), "prune1": o["prune1"][0].numpy()}
+        return run
+    from oracle import lightglue_oracle as O   # checker stand-in when the reference is not at hand (pinned against the reference's fixtures)
+    conf = O.make_conf(**{**conf_kw, **arch, "pruning_min_kpts": prune_th})
+    nsd = {k: v.numpy() for k, v in sd.items()}
+
+    def run(data):
+        o = O.forward(nsd, conf, data, backend="torch")
+        return {k: np.asarray(o[k])[0] if k != "stop" else int(np.asarray(o[k]).reshape(-1)[0]) for k in ("matches0", "matches1", "matching_scores0", "matching_scores1", "stop", "prune0", "prune1")}
+    return run
+
+
+def compare(name, got, ref, B):
+    """prints one line, returns True when the bar holds"""
+    flips = [0, 0]; maxd = 0.0; sq = 0.0; cnt = 0; stops_ok = True; prune_ok = True
+    for b in range(B):
+        r = ref[b]
+        for side in (0, 1):
+            gm = got[f"matches{side}"][b].cpu().numpy(); gs = got[f"matching_scores{side}"][b].cpu().numpy()
+            same = gm == r[f"matches{side}"]
+            flips[side] += int((~same).sum())
+            d = np.abs(gs - r[f"matching_scores{side}"])[same]
+            if d.size:
+                maxd = max(maxd, float(d.max())); sq += float((d ** 2).sum()); cnt += d.size
+            gp = got[f"prune{side}"][b].cpu().numpy()
+            prune_ok &= bool(np.array_equal(gp.astype(np.float64), np.asarray(r[f"prune{side}"], np.float64)))
+        gstop = int(got["stop"]) if not torch.is_tensor(got["stop"]) else int(got["stop"][b])
+        stops_ok &= gstop == r["stop"]
+    ok = flips == [0, 0] and maxd <= SCORE_TOL and stops_ok and prune_ok
+    print(f"| {name} | {flips[0]} / {flips[1]} | {maxd:.2e} | {np.sqrt(sq / max(cnt, 1)):.2e} | {'equal' if stops_ok else 'DIFFER'} | {'equal' if prune_ok else 'DIFFER'} | {'ok' if ok else 'OUTSIDE THE BAR'} |", flush=True)
+    return ok
+
+
+def layer_statistics(sd, arch, data):
+    from oracle import lightglue_oracle as O
+    conf = O.make_conf(depth_confidence=-1, width_confidence=-1, **arch)
+    nsd = {k: v.numpy() for k, v in sd.items()}
+    L = arch["n_layers"]
+    tr = {"_full_layers": tuple(range(L))}
+    g = lambda d, k: None if d.get(k) is None else np.asarray(d[k])[0]
+    d0, d1 = data["image0"], data["image1"]
+    O.forward_pair(nsd, conf, g(d0, "keypoints"), g(d1, "keypoints"), g(d0, "descriptors"), g(d1, "descriptors"), g(d0, "image_size"), g(d1, "image_size"),
+                   g(d0, "scales"), g(d0, "oris"), g(d1, "scales"), g(d1, "oris"), trace=tr, backend="torch")
+    spread = lambda q, k: float(np.median((lambda lg: lg.max(-1) - lg.min(-1))(np.einsum("hnd,hmd->hnm", np.asarray(q, np.float64), np.asarray(k, np.float64)) / 8.0)))
+    rms = lambda x: float(np.sqrt(np.mean(np.asarray(x, np.float64) ** 2)))
+    print("\n| layer | logit spread self (base e) | cross | residual rms | recipe D / E calibration target: spread 25, rms |")
+    print("|---|---|---|---|---|")
+    for i in range(L):
+        target = 3.5 * (27.0 / 3.5) ** (i / max(L - 1, 1))
+        print(f"| {i} | {spread(tr[f'l{i}_self0_q'], tr[f'l{i}_self0_k']):.1f} | {spread(tr[f'l{i}_cross_qk0'], tr[f'l{i}_cross_qk1']):.1f} | {rms(tr[f'desc0_l{i}']):.2f} | {target:.1f} |")
+    norms = np.linalg.norm(np.asarray(d0["descriptors"])[0], axis=-1)
+    print(f"\ndescriptor norms of the inputs: min {norms.min():.2f} median {np.median(norms):.2f} max {norms.max():.2f} (the 1e-3 bar is claimed for norms <= ~30, include/lightglue_amd.h)")
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("checkpoint"); ap.add_argument("features", nargs="?")
+    ap.add_argument("--reference", default=None, help="path of a checkout of the reference repository (or of its lightglue/lightglue.py)")
+    ap.add_argument("--sizes", type=int, nargs="*", default=[512, 1024, 2048]); ap.add_argument("--pairs", type=int, default=2)
+    ap.add_argument("--fixture", default=None, help="name of a tests/golden fixture whose inputs AND reference outputs are replayed with the checkpoint's weights")
+    ap.add_argument("--cpu-only", action="store_true", help="no GPU: print the checkpoint's statistics (and reference vs oracle) only")
+    ap.add_argument("--prune-threshold", type=int, default=1536, help="pruning_min_kpts on BOTH sides (the reference's flash value, ref :339-344)")
+    a = ap.parse_args()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+
+    sd, arch, legacy = load_checkpoint(a.checkpoint)
+    ref_mod, ref_path = find_reference(a.reference)
+    print(f"checkpoint {a.checkpoint}: {len(sd)} tensors, {'released (legacy) key names' if legacy else 'module-tree key names'}, {arch}")
+    print(f"CPU fp32 side: {'the unmodified reference ' + ref_path if ref_mod else 'oracle/lightglue_oracle.py (torch-kernel backend; the reference was not found — pass --reference)'}")
+    gpu = torch.cuda.is_available() and not a.cpu_only
+    if not gpu and not a.cpu_only:
+        sys.exit("no GPU visible: lightglue_amd has no CPU path — run on an MI355X box, or pass --cpu-only for the statistics alone")
+
+    cases = []   # (label, data numpy dict [B, ...], conf_kw)
+    adaptive_kw = dict(depth_confidence=0.95, width_confidence=0.99)
+    fixed_kw = dict(depth_confidence=-1, width_confidence=-1)
+    extra = dict(add_scale_ori=True) if arch["add_scale_ori"] else {}
+    for n in a.sizes:
+        data = synth.make_batch(4000 + n, a.pairs, n, n, arch["input_dim"], **extra)
+        cases += [(f"synthetic N=M={n} fixed depth", data, fixed_kw), (f"synthetic N=M={n} adaptive", data, adaptive_kw)]
+    if a.features:
+        z = np.load(a.features)
+        img = lambda i: {k: z[f"{k}{i}"][None].astype(np.float32) for k in ("keypoints", "descriptors", "scales", "oris") if f"{k}{i}" in z}
+        data = {"image0": img(0), "image1": img(1)}
+        for i in (0, 1):
+            data[f"image{i}"]["image_size"] = (z[f"image_size{i}"].astype(np.float32)[None] if f"image_size{i}" in z else
+                                                (data[f"image{i}"]["keypoints"][0].max(0) + 1)[None].astype(np.float32))
+        cases += [(f"{a.features} fixed depth", data, fixed_kw), (f"{a.features} adaptive", data, adaptive_kw)]
+    ok = True
+    stats_data = cases[0][1] if cases else synth.make_batch(4512, 1, 512, 512, arch["input_dim"], **extra)
+
+    if gpu:
+        for attn in (None, "fp16"):
+            print(f"\n## precision f16x3{'' if attn is None else ', attention_precision=fp16 (fast opt-in; NOT held to the bar)'}\n")
+            print("| case | index mismatches side 0 / 1 | max \\|d score\\| | rms | stop layers | prune counters | bar |")
+            print("|---|---|---|---|---|---|---|")
+            for label, data, conf_kw in cases:
+                B = data["image0"]["keypoints"].shape[0]
+                run = cpu_side(ref_mod, sd, arch, conf_kw, a.prune_threshold)
+                refs = [run({k: {kk: vv[b:b + 1] for kk, vv in v.items()} for k, v in data.items()}) for b in range(B)]
+                model = LightGlue(features=None, attention_precision=attn, pruning_min_kpts=a.prune_threshold, **arch, **conf_kw).eval()
+                model.load_state_dict(sd, strict=False)
+                td = {k: {kk: torch.from_numpy(vv).cuda() for kk, vv in v.items()} for k, v in data.items()}
+                good = compare(label, model(td), refs, B)
+                ok &= good or attn is not None
+            if a.fixture and attn is None:
+                from conftest import load_golden
+                import make_golden  # noqa: F401  (tools/ is on the path of the tests' helpers)
+                meta, gold = load_golden(a.fixture)
+                case = meta["case"]
+                _, data = make_golden.case_inputs(case)
+                fx_kw = {**arch, **case["conf"]}                      # the fixture's own conf (it may name input_dim / add_scale_ori itself)
+                model = LightGlue(features=None, pruning_min_kpts=case.get("prune_th", -1), **fx_kw).eval(); model.load_state_dict(sd, strict=False)
+                if case.get("static_lengths"):
+                    model.static_lengths = list(case["static_lengths"])
+                td = {k: {kk: torch.from_numpy(vv).cuda() for kk, vv in v.items()} for k, v in data.items()}
+                refs = [{k: (gold[k][b] if k != "stop" else int(gold[k][b])) for k in ("matches0", "matches1", "matching_scores0", "matching_scores1", "stop", "prune0", "prune1")}
+                        for b in range(case["B"])]
+                ok &= compare(f"fixture {a.fixture} (reference outputs stored in tests/golden)", model(td), refs, case["B"])
+    layer_statistics(sd, arch, {k: {kk: vv[:1] for kk, vv in v.items()} for k, v in stats_data.items()})
+    print("\nRESULT:", "inside the bar (0 index mismatches, |d score| <= 1e-3, stop layers and prune counters equal) on every default-precision case" if ok else "OUTSIDE THE BAR on at least one default-precision case")
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, str(ROOT / "tools"))
+    main()

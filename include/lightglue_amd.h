@@ -178,6 +178,8 @@ int lg_unpack_wire(const lg_unpack_io* io, void* hip_stream);
  *   "attn_rows"    -  query rows per attention wave: 16 | 32 | 64 (bit-identical outputs; the split attention has 16 | 32).  Unset:
  *                     32, and 16 when a launch has fewer 128-row workgroups than the chip has CUs (single pairs); setting it pins
  *                     the shape
+ *   "adapt_gather" 1  adaptive width: the SelfBlock projection behind a pruning step gathers its rows through the decide kernel's index map and writes
+ *                     them compacted into a second buffer set (no compaction launch; bit-identical to 0 = the in-place compaction kernel)
  *   "attn_dma"     1  single-plane 16-bit attention, 32 rows per wave: K / V^T tiles reach LDS by DMA (two buffers, one barrier per
  *                     tile, 4 waves per SIMD); 0 = the register-staged kernel (bit-identical).  The split attention is always DMA
  *   "tail_row_tiles" 0  16-row tiles per fused-tail workgroup: 4 (64 rows) | 2 | 1, 0 = by grid fill (small grids take the

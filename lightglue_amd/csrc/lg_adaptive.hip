@@ -55,6 +55,7 @@ __global__ __launch_bounds__(DNT) void adapt_decide_kernel(AdaptArgs a) {
             return;
         }
     }
+    if (a.gather && tid == 0) a.xsel[pair] = a.xnext;   // the pair continues: proj_gather_kernel moves its rows to the other buffer set
     for (int image = 0; image < 2; ++image) {
         const int seg = 2 * pair + image;
         const int L = image ? len1 : len0;
@@ -63,23 +64,32 @@ __global__ __launch_bounds__(DNT) void adapt_decide_kernel(AdaptArgs a) {
             continue;
         }
         const int base = seg_row_base(a.rs, seg);
+        int* prune = image ? a.prune1 + (long long)pair * a.n1 : a.prune0 + (long long)pair * a.n0;
         int running = 0;                                 // uniform across the block
         for (int r0 = 0; r0 < L; r0 += DNT) {
             const int r = r0 + tid;
             bool keep = false;
+            int v = 0;
             if (r < L) {
                 keep = a.mscore[base + r] > a.width_conf;               // ref :640 (width_conf = 1 - width_confidence)
                 if (a.do_stop) keep = keep || (a.conf[base + r] <= a.conf_thr);  // ref :641-642
+                if (a.gather) v = a.ind[base + r];                      // read BEFORE the barriers below: the in-place index compaction writes rows <= r
             }
             const unsigned long long bal = __ballot(keep);
             const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
-            __syncthreads();                             // sh_cnt reuse
+            __syncthreads();                             // sh_cnt reuse (and: every index-set read of this chunk has completed — __syncthreads waits vmcnt(0))
             if (lane == 0) sh_cnt[wave] = __popcll(bal);
             __syncthreads();
             int woff = 0, all = 0;
 #pragma unroll
             for (int w = 0; w < DNW; ++w) { const int c = sh_cnt[w]; woff += w < wave ? c : 0; all += c; }
-            if (r < L) a.dst[base + r] = keep ? (running + woff + prefix) : -1;
+            if (r < L) {
+                const int d = keep ? (running + woff + prefix) : -1;
+                if (!a.gather) a.dst[base + r] = d;
+                else if (keep) {   // d <= r and rows < r0 were read by earlier iterations: in place is safe (ref :554-558: ind = ind[keep]; prune[:, ind] += 1)
+                    a.src[base + d] = r; a.ind[base + d] = v; prune[v] += 1;
+                }
+            }
             running += all;
         }
         __syncthreads();
@@ -196,7 +206,7 @@ int compact_chunk_rows() { return CROWS; }
 
 hipError_t launch_adapt(const AdaptArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(adapt_decide_kernel, dim3(a.rs.B), dim3(DNT), 0, s, a);
-    if (a.do_prune) {
+    if (a.do_prune && !a.gather) {   // gather mode: the next SelfBlock projection moves the rows (proj_gather_kernel)
         const int items = 2 * a.rs.B * a.compact_chunks;   // dealt by ticket: the grid size is a throughput choice only (one workgroup per CU of an MI355X)
         hipLaunchKernelGGL(adapt_compact_kernel, dim3(items < 256 ? items : 256), dim3(256), 0, s, a);
     }

@@ -122,6 +122,10 @@ struct lg_engine {
     void *Q, *K, *VT;
     int *IND, *DST, *LEN, *LEN_ORIG, *LEN_OLD, *ACTIVE, *FINAL_LAYER, *ARG0, *ARG1;
     int* RANGEF = nullptr;   // [B] range-guard flags (LG_FLAG_CHECK_FINITE), zeroed by init_state_kernel
+    // gather path of the adaptive width (round 6, option "adapt_gather", default on): a second set of residual / rotary buffers — the SelfBlock projection behind
+    // a pruning step reads rows from one set and writes the compacted rows to the other (lg_proj.hip proj_gather_kernel) —, and which set each pair's rows are in
+    float *X2 = nullptr, *COS2 = nullptr, *SIN2 = nullptr; int* XSEL = nullptr;
+    bool adapt_gather = true;
     int debug_stop = -1;
     // ---- per-kernel-class HIP-event timing (bench.py roofline leg)
     bool profiling = false, prof_open = false;
@@ -210,9 +214,10 @@ const HostTensor* find(const lg_engine* e, const std::string& name, std::initial
 }
 
 __global__ void init_state_kernel(int B, int n0, int n1, int L, const int* num0, const int* num1, int* len, int* len_orig, int* len_old,
-                                  int* active, int* final_layer, int* prune0, int* prune1, int* range_flag = nullptr, int* device_err = nullptr) {
+                                  int* active, int* final_layer, int* prune0, int* prune1, int* range_flag = nullptr, int* device_err = nullptr, int* xsel = nullptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (range_flag && i < B) range_flag[i] = 0;
+    if (xsel && i < B) xsel[i] = 0;
     if (device_err && i == 0) *device_err = 0;
     auto count = [](const int* num, int pair, int n) { int v = num ? num[pair] : n; return v < 0 ? 0 : (v > n ? n : v); };
     if (len && i < B) {
@@ -356,7 +361,8 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
         add(R * (size_t)e->cfg.input_dim * 4);                  // XIN
         for (int i = 0; i < 3; ++i) add(R * 256 * as);          // Q K VT
         add(R * 4); add(R * 4);                                 // IND DST
-        for (int i = 0; i < 6; ++i) add((size_t)nB * 2 * 4);    // LEN LEN_ORIG LEN_OLD ACTIVE FINAL_LAYER RANGEF
+        for (int i = 0; i < 7; ++i) add((size_t)nB * 2 * 4);    // LEN LEN_ORIG LEN_OLD ACTIVE FINAL_LAYER RANGEF XSEL
+        add(R * 256 * 4); add(R * 32 * 4); add(R * 32 * 4);     // X2 COS2 SIN2 (gather path)
         add(R / 32 * 8 + 256);                                  // CFLAGS: 2B * max(cap0, cap1) / chunk rows (>= 32) ints, + the error word and the work-item ticket
         add(R * 16); add(R * 16);                               // TAILDBG TAILDBG2 (16 bytes per row: [R / 64 workgroups][8 waves][8 stamps], or [R / 128][16 half-waves ...] of the split attention's taps)
         total += 4096;
@@ -388,6 +394,8 @@ int ensure_workspace(lg_engine* e, int B, int n0, int n1) {
     e->LEN = (int*)take("LEN", (size_t)B * 2 * 4); e->LEN_ORIG = (int*)take("LEN_ORIG", (size_t)B * 2 * 4); e->LEN_OLD = (int*)take("LEN_OLD", (size_t)B * 2 * 4);
     e->ACTIVE = (int*)take("ACTIVE", (size_t)B * 4); e->FINAL_LAYER = (int*)take("FINAL_LAYER", (size_t)B * 4);
     e->RANGEF = (int*)take("RANGEF", (size_t)B * 4);
+    e->XSEL = (int*)take("XSEL", (size_t)B * 4);
+    e->X2 = (float*)take("X2", R * 256 * 4); e->COS2 = (float*)take("COS2", R * 32 * 4); e->SIN2 = (float*)take("SIN2", R * 32 * 4);
     e->CFLAGS = (int*)take("CFLAGS", (size_t)2 * B * ((c0 > c1 ? c0 : c1) / compact_chunk_rows()) * 4 + 256); e->cflags_clean = false;
     e->TAILDBG = (long long*)take("TAILDBG", R * 16); e->TAILDBG2 = (long long*)take("TAILDBG2", R * 16);
     if (ar.used > e->ws_bytes) return fail(LG_ERR_STATE, "workspace carve overflow");
@@ -660,6 +668,7 @@ int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
     if (std::strcmp(key, "fused_next") == 0) { e->fused_next = value != 0; return LG_OK; }
     if (std::strcmp(key, "fused_prep") == 0) { e->fused_prep = value != 0; return LG_OK; }
     if (std::strcmp(key, "attn_dma") == 0) { e->attn_dma = value != 0; return LG_OK; }
+    if (std::strcmp(key, "adapt_gather") == 0) { e->adapt_gather = value != 0; return LG_OK; }
     if (std::strcmp(key, "attn_rows") == 0) { if (value != 16 && value != 32 && value != 64) return fail(LG_ERR_INVALID, "attn_rows must be 16, 32 or 64"); e->attn_rows = value; e->attn_auto_rows = false; return LG_OK; }
     if (std::strcmp(key, "tail_row_tiles") == 0) { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(LG_ERR_INVALID, "tail_row_tiles must be 0 (automatic), 1, 2 or 4"); e->tail_row_tiles = value; return LG_OK; }
     if (std::strcmp(key, "profile_only") == 0) { e->prof_only = value; return LG_OK; }   // kernel class index, -1 = all classes
@@ -882,7 +891,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
 
     int* const device_err = e->CFLAGS + (size_t)2 * B * ((c0 > c1 ? c0 : c1) / compact_chunk_rows());   // error word + compaction ticket behind the chunk flags (lg_adaptive.hip)
     hipLaunchKernelGGL(init_state_kernel, dim3(64), dim3(256), 0, s, B, n0, n1, L, io->num0, io->num1, e->LEN, e->LEN_ORIG, e->LEN_OLD, e->ACTIVE, e->FINAL_LAYER,
-                       do_prune ? io->prune0 : nullptr, do_prune ? io->prune1 : nullptr, e->RANGEF, device_err);
+                       do_prune ? io->prune0 : nullptr, do_prune ? io->prune1 : nullptr, e->RANGEF, device_err, e->XSEL);
     int* const range_flag = check_finite ? e->RANGEF : nullptr;
     // prep (+ descriptor copy) as its own launch, or — input_dim == 256, no debug stop — inside the first projection launch (lg_proj.hip proj_first_kernel)
     const bool fuse_prep = e->fused_prep && e->cfg.input_dim == D && e->debug_stop < 0 && e->tail_timing != 2;
@@ -909,13 +918,17 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
     STEP_DONE();
     const long long qkv_plane = ap == PREC_F16X3 ? (long long)R * 256 : 0;   // split attention: hi plane, then lo plane, of q / k / v^T
 
+    // current set of residual / rotary buffers: set 0 = X / COS / SIN, set 1 = X2 / COS2 / SIN2; flipped by every gather projection (adaptive width)
+    int xcur = 0;
+    float* Xs[2] = {e->X, e->X2}; float* Cs[2] = {e->COS, e->COS2}; float* Ss[2] = {e->SIN, e->SIN2};
+    bool gather_pending = false;   // the decide step of the previous layer ran in gather mode: the next SelfBlock projection moves the rows
     auto make_proj = [&](int layer, int blk) {   // q/k/v projection of block `blk` of `layer` (lg_proj.hip / fused into lg_tail.hip)
         ProjArgs pj{};
-        pj.rs = rs_act; pj.X = e->X; pj.R = R; pj.q = e->Q; pj.k = e->K; pj.vt = e->VT; pj.plane = qkv_plane;
+        pj.rs = rs_act; pj.X = Xs[xcur]; pj.R = R; pj.q = e->Q; pj.k = e->K; pj.vt = e->VT; pj.plane = qkv_plane;
         pj.W = blk == 0 ? e->w_sqkv_p + (size_t)layer * e->sqkv_layer_bytes : e->w_cqkv_p + (size_t)layer * e->cqkv_layer_bytes;
         pj.bias = blk == 0 ? e->b_sqkv + (size_t)layer * 768 : e->b_cqkv + (size_t)layer * 512;
         pj.Nout = blk == 0 ? 768 : 512; pj.n_qk_groups = blk == 0 ? 2 : 1;
-        pj.cosb = blk == 0 ? e->COS : nullptr; pj.sinb = blk == 0 ? e->SIN : nullptr;
+        pj.cosb = blk == 0 ? Cs[xcur] : nullptr; pj.sinb = blk == 0 ? Ss[xcur] : nullptr;
         pj.dbg = nullptr; pj.range_flag = range_flag;
         return pj;
     };
@@ -924,10 +937,13 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
     const bool fuse_next = e->fused_next && e->fused_tail && (e->tail_timing == 0 || e->tail_timing == 5 || e->tail_timing == 6) &&
                            e->debug_stop < 0 && launch_tail_supports_next(prec, ap);
     const bool prune_possible = do_prune && (n0 > e->cfg.pruning_min_kpts || n1 > e->cfg.pruning_min_kpts);
+    // gather path: the product configuration only (the per-op / debug-stop paths keep the in-place compaction kernel, which the tests compare it with)
+    const bool use_gather = e->adapt_gather && e->fused_tail && e->debug_stop < 0 && e->tail_timing == 0;
     bool proj_done = false, final_done = false;
     auto make_final = [&](const RowSpace& rs, int layer, bool per_pair) {   // final projection (ref :289-291: / d**0.25), lg_proj.hip / fused into the last tail
         FinalArgs f{};
-        f.rs = rs; f.X = e->X; f.R = R; f.out = e->MD; f.scale = 0.25f;
+        f.rs = rs; f.X = per_pair ? e->X : Xs[xcur]; f.R = R; f.out = e->MD; f.scale = 0.25f;
+        if (per_pair) { f.X2 = e->X2; f.xsel = e->XSEL; }    // XSEL stays 0 unless a gather projection ran
         f.W = e->w_final_p + (per_pair ? 0 : (size_t)layer * e->final_layer_bytes); f.bias = e->b_final + (per_pair ? 0 : (size_t)layer * D);
         f.layer_of_pair = per_pair ? e->FINAL_LAYER : nullptr; f.w_layer_bytes = (long long)e->final_layer_bytes;
         return f;
@@ -948,6 +964,15 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
                         HIPCHK(launch_proj(prec, ap, pj, s));
                     }
                 }
+                else if (gather_pending && blk == 0) {
+                    // the rows of every pair that prunes move to the other buffer set on their way into the projection; pairs that do not prune at this
+                    // layer are copied as they are (identity map): one buffer set is current for the whole batch
+                    GatherArgs ga{};
+                    ga.Xold = Xs[xcur]; ga.cos_old = Cs[xcur]; ga.sin_old = Ss[xcur]; ga.Xnew = Xs[xcur ^ 1]; ga.cos_new = Cs[xcur ^ 1]; ga.sin_new = Ss[xcur ^ 1];
+                    ga.src = e->DST; ga.len_old = e->LEN_OLD;
+                    HIPCHK(launch_proj_gather(prec, ap, pj, ga, s));
+                    xcur ^= 1; gather_pending = false;
+                }
                 else HIPCHK(launch_proj(prec, ap, pj, s));
                 TRY(prof_end(e, s));
             }
@@ -965,7 +990,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
             STEP_DONE();
             if (e->fused_tail) {   // out_proj + ffn.0 + LayerNorm + GELU + ffn.3 + residual in one kernel (lg_tail.hip)
                 TailArgs ta{};
-                ta.rs = rs_act; ta.X = e->X; ta.CTX = e->CTX; ta.range_flag = range_flag;
+                ta.rs = rs_act; ta.X = Xs[xcur]; ta.CTX = e->CTX; ta.range_flag = range_flag;
                 ta.Wcat = (blk ? e->w_ctail_cat : e->w_stail_cat) + (size_t)i * e->tail_cat_layer_bytes;
                 ta.bcat = (blk ? e->b_ccat : e->b_scat) + (size_t)i * 512;
                 ta.gamma = (blk ? e->ln_c_g : e->ln_s_g) + (size_t)i * 512; ta.beta = (blk ? e->ln_c_b : e->ln_s_b) + (size_t)i * 512;
@@ -1060,6 +1085,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
             ad.rs = rs_act; ad.len = e->LEN; ad.active = e->ACTIVE; ad.len_old = e->LEN_OLD; ad.final_layer = e->FINAL_LAYER;
             ad.ind = e->IND; ad.dst = e->DST; ad.prune0 = io->prune0; ad.prune1 = io->prune1; ad.n0 = n0; ad.n1 = n1; ad.len_orig = e->LEN_ORIG;
             ad.conf = e->CONF; ad.mscore = e->MSCORE; ad.X = e->X; ad.cosb = e->COS; ad.sinb = e->SIN;
+            if (use_gather && prune_now) { ad.gather = 1; ad.src = e->DST; ad.xsel = e->XSEL; ad.xnext = xcur ^ 1; gather_pending = true; }
             ad.layer = i;
             // ref :631-634 threshold (float32 buffer), :656 and :640 compare in float32
             ad.conf_thr = (float)std::fmin(std::fmax(0.8 + 0.1 * std::exp(-4.0 * i / L), 0.0), 1.0);

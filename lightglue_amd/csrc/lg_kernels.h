@@ -51,6 +51,17 @@ struct ProjArgs {
     int* range_flag;                                 // [B] or nullptr: LG_FLAG_CHECK_FINITE — set to 1 when a q / k / v value of a live row is not |v| < 65504
 };
 hipError_t launch_proj(int prec, int attn_prec, const ProjArgs& a, hipStream_t s);
+// The SelfBlock projection that follows a pruning step, with the row compaction folded in (round 6): new row r of a segment is the old row src[r]
+// (adapt_decide_kernel's inverse map; identity where len_old[seg] < 0), read from the buffers the rows lived in and written — residual row, rotary rows —
+// to the OTHER set of buffers (the engine flips the two sets at every pruning layer), so no workgroup ever overwrites a row another one still has to read:
+// the in-place compaction kernel, its flags / tickets and its launch are gone from the product path.
+struct GatherArgs {
+    const float* Xold; const float* cos_old; const float* sin_old;
+    float* Xnew; float* cos_new; float* sin_new;
+    const int* src;       // [R] segment-local source row of every new row
+    const int* len_old;   // [2B] length before this layer's pruning, -1 = pruning not applied to the segment at this layer
+};
+hipError_t launch_proj_gather(int prec, int attn_prec, const ProjArgs& a, const GatherArgs& g, hipStream_t s);
 
 // ---------------------------------------------------------------- final projection (lg_proj.hip; ref lightglue.py:289-291)
 // MD[row, :] = (final_proj(x[row]) ) / 256^0.25 with the weights of the layer each pair stopped at: the same workgroup shape and operand
@@ -63,6 +74,7 @@ struct FinalArgs {
     const int* layer_of_pair; long long w_layer_bytes;   // optional per-pair layer select; nullptr: W / bias point at the layer to use
     float* out; float scale;                         // [R][256] fp32
     int R;
+    const float* X2; const int* xsel;                // optional: pair p's rows live in X2 when xsel[p] != 0 (the gather path flips buffers per pruning layer; a stopped pair stays where it was)
 };
 hipError_t launch_final_proj(int prec, const FinalArgs& a, hipStream_t s);
 
@@ -164,6 +176,9 @@ struct AdaptArgs {
     int compact_epoch;      // > 0, different for every launch (never reset: stale flags of earlier launches compare unequal)
     int* compact_err;       // set to 1 if a bounded flag wait expired (never expected): the chunk's stores are SKIPPED and the forward reports LG_ERR_DEVICE in io->status
     int* compact_ticket;    // work-item counter of adapt_compact_kernel (reset by adapt_decide_kernel of the same launch_adapt)
+    // gather mode (round 6; the product path): no compaction launch — adapt_decide_kernel writes the inverse map `src` (new row -> old row), compacts the index
+    // set in place, bumps the prune counters (ref :555-558) and records in xsel[pair] which buffer set a continuing pair's rows move to (proj_gather_kernel)
+    int gather; int* src; int* xsel; int xnext;
 };
 hipError_t launch_adapt(const AdaptArgs& a, hipStream_t s);
 int compact_chunk_rows();   // rows per compaction work item (lg_adaptive.hip CROWS)

@@ -175,6 +175,100 @@ hipError_t launch_proj_first(int prec, int attn_prec, const ProjArgs& a, const P
     return hipErrorInvalidValue;
 }
 
+// ---- the SelfBlock projection behind a pruning step, with the compaction folded in (lg_kernels.h GatherArgs): proj_first_kernel's shape — the workgroup fetches the
+// residual rows and the rotary rows of its 64 NEW keypoint rows from wherever they lived (src map), stores them at their new place in the other buffer set and
+// projects them.  The same fp32 values reach the same tile positions as after an in-place compaction, so q / k / v are bit-identical to that path.
+template <int PREC, class TA>
+__global__ __launch_bounds__(PTHREADS) void proj_gather_kernel(ProjArgs a, GatherArgs ga) {
+    typedef typename PJ<PREC>::Tag Tag;
+    constexpr int EPC = Tag::EPC, NV = EPC / 4;
+    constexpr int KE = PJL<PREC>::KE, STAGES = PJL<PREC>::STAGES, TILE = PJL<PREC>::TILE, A_PLANE = PJL<PREC>::A_PLANE, A_BYTES = PJL<PREC>::A_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* smA = smem;
+    float* ldsC = reinterpret_cast<float*>(smem + A_BYTES);            // [64][32] cos, then [64][32] sin
+    float* ldsS = ldsC + PBM * 32;
+
+    const TileLoc t = locate_tile(a.rs, blockIdx.x, PBM);
+    const int len = a.rs.len[t.seg];
+    if (t.r0 >= len) return;
+    if (a.rs.active && !a.rs.active[t.pair]) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, g = lane >> 4;
+    const int srow = tid >> 3, sslot = tid & 7;
+    const int r = t.r0 + srow, rc = r < len ? r : len - 1;             // rows past the segment's count: a finite copy of its last row (never stored)
+    const long long base = t.grow0 - t.r0;                             // first row of the segment
+    const int sr = ga.len_old[t.seg] >= 0 ? ga.src[base + rc] : rc;
+    const long long in_row = base + sr;
+    const float* src = ga.Xold + in_row * 256 + sslot * EPC;
+    f32x4 hreg[STAGES][NV];
+#pragma unroll
+    for (int st = 0; st < STAGES; ++st)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) hreg[st][j] = *reinterpret_cast<const f32x4*>(src + st * KE + 4 * j);
+    {
+        const f32x4 c4 = *reinterpret_cast<const f32x4*>(ga.cos_old + in_row * 32 + sslot * 4);
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(ga.sin_old + in_row * 32 + sslot * 4);
+        *reinterpret_cast<f32x4*>(ldsC + srow * 32 + sslot * 4) = c4;
+        *reinterpret_cast<f32x4*>(ldsS + srow * 32 + sslot * 4) = s4;
+        if (r < len) {
+            const long long grow = t.grow0 + srow;
+            *reinterpret_cast<f32x4*>(ga.cos_new + grow * 32 + sslot * 4) = c4;
+            *reinterpret_cast<f32x4*>(ga.sin_new + grow * 32 + sslot * 4) = s4;
+        }
+    }
+    {
+        const int off = pj_tile_off(srow, sslot);
+        float* xdst = ga.Xnew + (long long)(t.grow0 + srow) * 256 + sslot * EPC;
+#pragma unroll
+        for (int st = 0; st < STAGES; ++st) {
+            char* tile = smA + st * TILE;
+            if (r < len) {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) *reinterpret_cast<f32x4*>(xdst + st * KE + 4 * j) = hreg[st][j];
+            }
+            if constexpr (PREC == PREC_F32) {
+                *reinterpret_cast<f32x4*>(tile + off) = hreg[st][0];
+            } else if constexpr (PJ<PREC>::APART == 2) {
+                u32x4 hi, lo;
+                split8<Tag>(hreg[st][0], hreg[st][1], hi, lo);
+                *reinterpret_cast<u32x4*>(tile + off) = hi;
+                *reinterpret_cast<u32x4*>(tile + A_PLANE + off) = lo;
+            } else {
+                *reinterpret_cast<u32x4*>(tile + off) = pack8<Tag>(hreg[st][0], hreg[st][1]);
+            }
+        }
+    }
+    __syncthreads();   // the tile's rotary rows are in LDS
+    RopeRows<4> rr;
+    {
+        const int f0 = ((32 * w) & 63) / 2 + 4 * g;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int row = pj_row<4>(mt, lr);
+            rr.c[mt] = *reinterpret_cast<const f32x4*>(ldsC + row * 32 + f0);
+            rr.s[mt] = *reinterpret_cast<const f32x4*>(ldsS + row * 32 + f0);
+        }
+    }
+    proj_compute<PREC, TA, 3, 2>(a, t, smA, 0, &rr);
+}
+template <int PREC, class TA> static hipError_t launch_proj_gather_t(const ProjArgs& a, const GatherArgs& g, hipStream_t s) {
+    const int R = a.rs.B * (a.rs.cap0 + a.rs.cap1);
+    constexpr int smem = PJL<PREC>::A_BYTES + 2 * PBM * 32 * 4;
+    auto kern = proj_gather_kernel<PREC, TA>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(R / PBM), dim3(PTHREADS), smem, s, a, g);
+    return hipGetLastError();
+}
+hipError_t launch_proj_gather(int prec, int attn_prec, const ProjArgs& a, const GatherArgs& g, hipStream_t s) {
+    if (!(a.Nout == 768 && a.n_qk_groups == 2) || !g.Xold || !g.Xnew || !g.src || !g.len_old) return hipErrorInvalidValue;
+    if (prec == PREC_F32 && attn_prec == PREC_F32) return launch_proj_gather_t<PREC_F32, float>(a, g, s);
+    if (prec == PREC_BF16 && attn_prec == PREC_BF16) return launch_proj_gather_t<PREC_BF16, bf16_t>(a, g, s);
+    if (prec == PREC_F16 && attn_prec == PREC_F16) return launch_proj_gather_t<PREC_F16, f16_t>(a, g, s);
+    if (prec == PREC_F16X3 && attn_prec == PREC_F16X3) return a.plane > 0 ? launch_proj_gather_t<PREC_F16X3, f16_t>(a, g, s) : hipErrorInvalidValue;
+    if (prec == PREC_F16X3 && attn_prec == PREC_F16) return launch_proj_gather_t<PREC_QKV_F16W2, f16_t>(a, g, s);
+    return hipErrorInvalidValue;
+}
+
 // final projection of the log assignment as its own launch (adaptive depth: the weights of the layer each pair stopped at)
 template <int PREC>
 __global__ __launch_bounds__(PTHREADS) void final_proj_kernel(FinalArgs a) {
@@ -182,7 +276,7 @@ __global__ __launch_bounds__(PTHREADS) void final_proj_kernel(FinalArgs a) {
     const TileLoc t = locate_tile(a.rs, blockIdx.x, PBM);
     if (t.r0 >= a.rs.len[t.seg]) return;
     if (a.rs.active && !a.rs.active[t.pair]) return;
-    proj_load_tile<PREC>(a.X, t, smem);
+    proj_load_tile<PREC>((a.xsel && a.xsel[t.pair]) ? a.X2 : a.X, t, smem);   // gather path: a pair's rows live in the buffer set they were in when it stopped
     final_compute<PREC>(a, t, smem);
 }
 template <int PREC> static hipError_t launch_final_t(const FinalArgs& a, hipStream_t s) {

@@ -101,3 +101,38 @@ def test_verify_pretrained_on_a_released_format_checkpoint(tmp_path):
     line = [ln for ln in p.stdout.splitlines() if "fixture trained_stats_1024_b8" in ln][0]
     assert "| 0 / 0 |" in line and line.rstrip().endswith("| ok |"), line
     assert "RESULT: inside the bar" in p.stdout
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16x3/fp16", "fp32"])
+def test_gather_projection_equals_the_in_place_compaction(precision):
+    """Adaptive width without a compaction launch (engine option adapt_gather, default on): the SelfBlock projection behind a pruning step gathers its rows
+    through the decide kernel's inverse index map into a second buffer set.  The same fp32 rows reach the same tile positions as after the in-place
+    compaction kernel, so every output — indices, scores, stop layers, prune counters — must be BIT-identical with the option off: both images pruning,
+    only one image above the threshold, ragged counts with an empty image, pairs stopping at different layers (their rows stay in the buffer set they
+    were in: per-pair buffer select of the final projection), pruning without early stop, and the full log-assignment side output."""
+    require_gpu()
+    cases = [("C", dict(pruning_min_kpts=64), (17, 3, 300, 333), {}),
+             ("C", dict(), (201, 2, 2048, 2048), {}),                                   # cfg #3's shape: mixed stop depths, both images above 1536
+             ("C", dict(pruning_min_kpts=256), (33, 3, 260, 700), dict(nums=([260, 77, 0], [700, 5, 130]))),
+             ("B", dict(pruning_min_kpts=64, depth_confidence=-1), (41, 2, 500, 400), {}),   # pruning only: the last tail runs the final projection itself
+             ("C", dict(pruning_min_kpts=512), (55, 2, 700, 400), dict(log_assignment=True)),
+             ("D", dict(pruning_min_kpts=64), (61, 2, 640, 512), dict(recipe_d_data=True))]
+    for recipe, kw, (seed, B, n, m), opt in cases:
+        sd = synth.make_state_dict(0, recipe=recipe)
+        data = gpu_util.to_torch(synth.make_batch(seed, B, n, m, **(synth.RECIPE_D_DATA if opt.get("recipe_d_data") else {})))
+        if "nums" in opt:
+            data["image0"]["num_keypoints"] = torch.as_tensor(opt["nums"][0], dtype=torch.int32, device="cuda")
+            data["image1"]["num_keypoints"] = torch.as_tensor(opt["nums"][1], dtype=torch.int32, device="cuda")
+        model = gpu_util.make_model(sd, precision, **kw)
+        model.return_log_assignment = bool(opt.get("log_assignment"))
+        on = model(data)
+        again = model(data)                                  # the buffer sets flip inside a forward: a second forward must start from set 0 again
+        model.set_option("adapt_gather", 0)
+        off = model(data)
+        keys = ("matches0", "matches1", "matching_scores0", "matching_scores1", "prune0", "prune1") + (("log_assignment",) if opt.get("log_assignment") else ())
+        for key in keys:
+            assert torch.equal(on[key], off[key]), (recipe, key, n, m)
+            assert torch.equal(on[key], again[key]), (recipe, key, "second forward")
+        assert torch.equal(torch.as_tensor(on["stop"]), torch.as_tensor(off["stop"]))
+        if recipe == "C" and "nums" not in opt:
+            assert (on["prune0"] < torch.as_tensor(on["stop"]).reshape(-1, 1).to(on["prune0"].device)).any(), "the case must actually prune"

@@ -212,6 +212,33 @@ def golden_parity(gpu_out, n, B, recipe="A", config=2, m=None):
     return parity_block(gpu_out, refs, n, n, source=f"tests/golden/{name}.npz (real reference, CPU fp32) = pairs 0..{pairs - 1} of the timed batch")
 
 
+def bind_rank_to_gpu_numa(device_index: int) -> str:
+    """Multi-GPU runs: keep a rank's host threads (Python, HIP runtime, RCCL proxy) on the CPUs of ITS GPU's NUMA node — on an 8-GPU node the launcher otherwise
+    lets all ranks float over both sockets, and a rank whose launch thread sits on the far socket pays the cross-socket hop on every kernel launch and on the
+    [3][B] host-block copy of every step.  The GPU's PCI address comes from the HIP runtime, its CPUs from sysfs (local_cpulist).  Never fatal: returns what it did."""
+    try:
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        buf = C.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) != 0:
+            return "unchanged (hipDeviceGetPCIBusId failed)"
+        bdf = buf.value.decode().lower()
+        text = open(f"/sys/bus/pci/devices/{bdf}/local_cpulist").read().strip()
+        cpus = []
+        for part in text.split(","):
+            if part:
+                a, _, b = part.partition("-")
+                cpus += list(range(int(a), int(b or a) + 1))
+        cpus = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        if not cpus:
+            return f"unchanged (GPU {bdf}: empty local_cpulist)"
+        os.sched_setaffinity(0, cpus)
+        node = open(f"/sys/bus/pci/devices/{bdf}/numa_node").read().strip()
+        return f"GPU {bdf} -> NUMA node {node}, {len(cpus)} CPUs ({text})"
+    except Exception as exc:   # no sysfs entry, no permission, ...: run unpinned
+        return f"unchanged ({type(exc).__name__}: {exc})"[:200]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,6 +288,8 @@ def main():
     backend = os.environ.get("LG_BENCH_BACKEND", "nccl")
     if os.environ.get("LG_BENCH_ONE_GPU") == "1":
         local_rank = 0
+    # bound BEFORE the process group exists, so that RCCL's proxy threads are born inside the mask as well
+    rank_affinity = bind_rank_to_gpu_numa(local_rank) if world > 1 else "one GPU: not bound"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -366,6 +395,22 @@ def main():
     prof = model.profile_read(dev)
     model.profile(False, dev)
 
+    def tail_clock_mhz():
+        # the shader clock the chip gives the fused tail INSIDE a forward (power management): shader cycles between a workgroup's first and last stamp /
+        # its life on the 100 MHz wall clock, median over the workgroups of the last tail launch (profiling tap of the product library, tools/tail_wall.py)
+        try:
+            model.set_option("tail_timing", 1, dev); model(data); torch.cuda.synchronize(dev)
+            d = model.debug_read("TAILDBG", np.int64, dev).reshape(-1, 8, 8)
+            d = d[d[:, 0, 0] != 0]
+            t0 = (d[:, :, 6] & ((1 << 44) - 1)).min(1); t1 = (d[:, :, 7] & ((1 << 44) - 1)).max(1)
+            cyc = (d[:, :, 5] - d[:, :, 0]).max(1)
+            return round(float(np.median(cyc / ((t1 - t0) / 100.0))), 1) if len(d) else None
+        except Exception:
+            return None
+        finally:
+            model.set_option("tail_timing", 0, dev)
+
+    kernel_clock = tail_clock_mhz() if (rank == 0 and not args.no_calibration and args.precision == "f16x3" and not adaptive) else None   # (every tile live: no stale stamps)
     rccl = None
     sync_value = None
     if world > 1:
@@ -397,6 +442,7 @@ def main():
                 "ranks_seen": seen, "gather": "all_gather_into_tensor of one packed int32 buffer [pairs, 3n + 3m + 2] per step (matches0 | scores0 bits | matches1 | scores1 bits | stop | status | prune0 | prune1): every rank rebuilds the full output dict of forward() from it",
                 "gather_bytes_sent_per_rank": int(send.numel() * 4), "gather_bytes_received_per_rank": int(recv.numel() * 4),
                 "gather_ms_alone": e0.elapsed_time(e1) / 20, "gather_overlap": "gather, unpack kernel and the copy of the [3][B] host block run on a side stream behind an event, under step i+1's forward",
+                "rank0_cpu_affinity": rank_affinity,
                 "step_output_note": "the N > 1 step returns the same dict as the N = 1 step (see step_output): every rank rebuilds it for the WHOLE batch from the gathered rows"}
     elif not args.no_pipeline:
         # the reference's forward() is synchronous; the headline loop defers each step's host sync by one step.  The same K
@@ -532,6 +578,8 @@ def main():
             # shader clock this box sustains under a matrix-core-dense load, measured right before the timed region: the pool's
             # boxes differ by up to ~20 % for one binary, and most of it is this clock
             "effective_mfma_clock_mhz": sustained_mhz, "sustained_dense_bf16_tflops": sustained_tflops,
+            # the board's power limit is what bounds the two big kernels: the clock the fused tail actually ran at inside a forward, of 2 400 MHz nominal
+            "shader_clock_mhz_inside_tail_kernel": kernel_clock,
             "matches_per_pair": float((out["matches0"].cpu().numpy() > -1).sum(axis=1).mean()) if "matches0" in out else None,   # (one copy: no framework kernels behind the timed region either)
             "value_synchronous_forward": sync_value,   # pairs/s with model(data) per step (host sync inside every forward), N = 1 only
             "rccl": rccl,

@@ -186,6 +186,10 @@ def test_plain_bench_command_launches_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl"]["world"] == 2 and len(d["rccl"]["ranks_seen"]) == 2
     assert d["parity"]["index_mismatches"] == 0 and d["parity"]["unexplained"] == 0
+    # the N > 1 step hands back forward()'s own dict for the WHOLE batch, and every rank is bound to its GPU's NUMA node (or says why not)
+    assert d["step_output"] == {"matches": "list[64] of int64", "matches0": "int64", "matches1": "int64", "matching_scores0": "float32", "matching_scores1": "float32",
+                                "prune0": "float32", "prune1": "float32", "scores": "list[64] of float32", "stop": "int64"}, d["step_output"]
+    assert isinstance(d["rccl"]["rank0_cpu_affinity"], str) and d["rccl"]["rank0_cpu_affinity"]
 
 
 def test_bench_config_4_two_ranks_on_one_gpu():
@@ -225,6 +229,8 @@ def test_bench_default_is_config_2_and_reports_the_gather_probe():
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
     assert d["metric"] == "image-pairs/s at N=M=1024, 9 layers; match-index parity vs ref" and d["config"]["pairs_per_gpu"] == 32 and d["config"]["keypoints"] == 1024
     assert d["parity"]["pairs"] == 4 and d["parity"]["index_mismatches"] == 0
+    assert d["step_output"] == {"matches": "list[32] of int64", "matches0": "int64", "matches1": "int64", "matching_scores0": "float32", "matching_scores1": "float32",
+                                "prune0": "float32", "prune1": "float32", "scores": "list[32] of float32", "stop": "int64"}, d["step_output"]   # same keys / dtypes as at N > 1
     g = d["gather_probe_one_gpu"]
     assert "error" not in g, g
     assert g["matches_equal_plain_loop"] is True and g["ms_per_step_with_world1_gather"] > 0

@@ -150,6 +150,9 @@ def cpu_baseline(sd, n, m, gpu_out=None, budget_s=20.0, max_pairs=32, recipe="A"
         cmd = [sys.executable, str(ROOT / "oracle" / "cpu_leg.py"), "--n", str(n), "--m", str(m), "--dim", str(dim), "--recipe", recipe, "--wseed", str(wseed),
                "--conf", json.dumps(conf), "--threads", str(CPU_LEG_THREADS), "--budget", str(budget_s), "--max-pairs", str(max_pairs), "--out", out_npz]
         env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+        # glibc malloc: keep the forward's large temporaries (16 MB attention matrices, ...) in the heap instead of mmap / munmap per tensor — page-fault churn was
+        # the main source of the round-to-round wobble, and costs the CPU side ~25 % (build container: 3.21 -> 4.08 pairs/s, round spread 13 % -> 3.5 %)
+        env.update(MALLOC_TRIM_THRESHOLD_="4294967296", MALLOC_MMAP_THRESHOLD_="4294967296", MALLOC_TOP_PAD_="268435456")
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
         if p.returncode != 0:
             return {"error": p.stderr[-500:], "kind": "port"}, None
@@ -157,7 +160,7 @@ def cpu_baseline(sd, n, m, gpu_out=None, budget_s=20.0, max_pairs=32, recipe="A"
         z = np.load(out_npz)
         k = int(z["pairs"])
         refs = [{key: z[f"{key}_{i}"] for key in ("matches0", "matches1", "matching_scores0", "matching_scores1")} for i in range(k)]
-    res.update({"cpu_model": _cpu_model(), "logical_cores": os.cpu_count(),
+    res.update({"cpu_model": _cpu_model(), "logical_cores": os.cpu_count(), "allocator": "glibc malloc with MALLOC_MMAP_THRESHOLD_ / MALLOC_TRIM_THRESHOLD_ = 4 GiB (no mmap / munmap per tensor)",
                 "port_over_reference_time_ratio": PORT_OVER_REFERENCE_TIME,
                 "port_over_reference_source": "profiles/r03_cpu_reference.md (tools/cpu_reference_table.py: the unmodified reference and this port timed side by side in the build container); "
                                               "oracle/cpu_leg.py re-measures it wherever /root/reference is mounted (reference_pairs_per_s / port_pairs_per_s)"})

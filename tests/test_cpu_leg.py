@@ -30,7 +30,7 @@ def test_cpu_leg_process_contract(tmp_path):
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads(p.stdout.strip().splitlines()[-1])
     assert d["kind"] == "port" and d["unit"] == "image-pairs/s" and d["cores"] == len(d["cpus"]) <= 2 and d["value"] > 0
-    assert len(d["rounds_pairs_per_s"]) == 3 and d["round_spread"] >= 0
+    assert len(d["rounds_pairs_per_s"]) == 3 and d["round_spread"] >= 0 and len(d["round_median_forward_ms"]) == 3 and len(d["forward_ms_p10_p50_p90"]) == 3
     done, total = (int(x) for x in d["threads_pinned"].split(" ")[0::2][:2])
     assert done == total, d["threads_pinned"]                     # EVERY thread of the process sits inside the chosen cores
     assert set(d["cfg1_n512_b1"]) == {"1 thread(s)", f"{d['cores']} thread(s)"} or d["cores"] == 1

@@ -454,7 +454,7 @@ int lg_engine_profile_read(lg_engine* e, double* ms, int64_t* count, int32_t n) 
 }
 
 const char* lg_last_error(void) { return g_err.c_str(); }
-const char* lg_version(void) { return "lightglue_amd 0.3 (gfx950)"; }
+const char* lg_version(void) { return "lightglue_amd 0.4 (gfx950)"; }
 
 int lg_engine_create(const lg_config* cfg, lg_engine** out) {
     if (!cfg || !out) return fail(LG_ERR_INVALID, "null argument");

@@ -5,7 +5,7 @@
 #   configs on one GPU, B = 1 latency, SuperPoint extractor
 O=gpurun_out/round; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -q -n 4 > $O/gputests.log 2>&1; grep -E 'passed|failed|error' $O/gputests.log | tail -4   # (the full log is kept: a failure must be readable afterwards)
+python -m pytest tests -m gpu -q > $O/gputests.log 2>&1; grep -E 'passed|failed|error' $O/gputests.log | tail -4   # (the full log is kept: a failure must be readable afterwards)
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err
 python bench.py --attention fp16 --no-cpu-baseline > $O/bench_fast_attention.json 2>> $O/bench.err
@@ -42,3 +42,6 @@ timeout 400 python tools/bench_configs.py 2>&1 | grep -v amdgpu.ids | tail -13; 
 timeout 200 python tools/latency_b1.py 2>&1 | grep -v amdgpu.ids > $O/latency_b1.log; cat $O/latency_b1.log
 timeout 200 python tools/bench_superpoint.py 2>&1 | grep -v amdgpu.ids | tail -8 | tee $O/superpoint.log
 ( python tools/tail_timing.py f16x3 1; python tools/tail_timing.py f16x3 5; python tools/tail_wall.py ) 2>&1 | grep -v amdgpu.ids | tee $O/tail_timing.log
+# round 6: the clock the two big kernels get inside a forward (power management) and the board's power under the bench loop
+if [ -f build_variants/liblightglue_amd_attn_wall.so ]; then LIGHTGLUE_AMD_LIB=$PWD/build_variants/liblightglue_amd_attn_wall.so timeout 200 python tools/attn_wall.py 2>&1 | grep -v "^live\|amdgpu.ids" | tee $O/attn_wall_clock.log; fi
+( python bench.py --steps 2500 --warmup 5 --no-cpu-baseline --no-calibration --no-gather-probe > $O/bench_long.json 2>/dev/null & BP=$!; sleep 14; for i in 1 2 3 4 5; do rocm-smi --showpower --showclocks 2>&1 | grep -E "Power|sclk"; sleep 1.5; done; wait $BP ) > $O/rocm_smi_under_bench.log 2>&1; grep -E "Power|sclk" $O/rocm_smi_under_bench.log | tail -4

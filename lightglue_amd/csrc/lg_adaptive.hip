@@ -73,11 +73,14 @@ __global__ __launch_bounds__(DNT) void adapt_decide_kernel(AdaptArgs a) {
             if (r < L) {
                 keep = a.mscore[base + r] > a.width_conf;               // ref :640 (width_conf = 1 - width_confidence)
                 if (a.do_stop) keep = keep || (a.conf[base + r] <= a.conf_thr);  // ref :641-642
-                if (a.gather) v = a.ind[base + r];                      // read BEFORE the barriers below: the in-place index compaction writes rows <= r
+                if (a.gather) v = a.ind[base + r];                      // read (and waited for, below) BEFORE the barriers: the in-place index compaction writes rows <= r
             }
             const unsigned long long bal = __ballot(keep);
             const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
-            __syncthreads();                             // sh_cnt reuse (and: every index-set read of this chunk has completed — __syncthreads waits vmcnt(0))
+            // the in-place index compaction: every read of this chunk's index-set entries must have RETURNED before any wave stores below.  hipcc's __syncthreads
+            // does not wait for loads in flight (workgroup scope, one CU, one L1: its memory model needs no vmcnt there — seen in the ISA), so wait explicitly
+            if (a.gather) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                             // sh_cnt reuse
             if (lane == 0) sh_cnt[wave] = __popcll(bal);
             __syncthreads();
             int woff = 0, all = 0;

@@ -136,3 +136,16 @@ def test_gather_projection_equals_the_in_place_compaction(precision):
         assert torch.equal(torch.as_tensor(on["stop"]), torch.as_tensor(off["stop"]))
         if recipe == "C" and "nums" not in opt:
             assert (on["prune0"] < torch.as_tensor(on["stop"]).reshape(-1, 1).to(on["prune0"].device)).any(), "the case must actually prune"
+
+
+def test_randomised_soak_of_the_gather_and_sharded_paths():
+    """tools/stress_adaptive_paths.py, 14 seeded random cases (shapes, thresholds, ragged counts incl. empty images, recipes, precisions): gather projection ==
+    in-place compaction, second forward == first, PairShardedMatcher's world-of-one step == forward() — all bit for bit (the 80-case run is in profiles/)."""
+    require_gpu()
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    p = subprocess.run([sys.executable, str(root / "tools" / "stress_adaptive_paths.py"), "14", "7"], capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1500:]
+    assert "all bit-identical" in p.stdout

@@ -169,9 +169,10 @@ class PairShardedMatcher:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
             cur = torch.cuda.current_stream(dev)
-            ready = torch.cuda.Event(); ready.record(cur)
+            # everything the side stream writes is allocated (torch.empty: no kernel) BEFORE the event, and nothing on the compute stream touches it afterwards
             gathered = torch.empty((world * per_rank, width), dtype=torch.int32, device=dev)
             outs, info = _alloc_outputs(global_batch, m, n, with_prune, dev)
+            ready = torch.cuda.Event(); ready.record(cur)
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ready)
                 dist.all_gather_into_tensor(gathered, buf, group=self.group)
@@ -240,7 +241,9 @@ def _alloc_outputs(pairs: int, m: int, n: int, with_prune: bool, dev):
             "matching_scores0": new((pairs, m), torch.float32), "matching_scores1": new((pairs, n), torch.float32),
             "stop": new((pairs,), torch.int64), "prune0": new((pairs, m), pdt), "prune1": new((pairs, n), pdt),
             "_mlist": new((pairs, kmax, 2), torch.int64), "_mscores": new((pairs, kmax), torch.float32)}
-    return outs, torch.zeros((3, pairs), dtype=torch.int32, device=dev)
+    # the host block: NOT torch.zeros — a fill kernel on the compute stream could run after the side stream's unpack kernel has written the block; every pair of
+    # the batch sits in exactly one shard, so lg_unpack_wire (and the CPU form below) writes all 3 x pairs entries
+    return outs, torch.empty((3, pairs), dtype=torch.int32, device=dev)
 
 
 def _unpack_cuda(g: torch.Tensor, dest, pairs: int, m: int, n: int, with_prune: bool, outs: dict, info: torch.Tensor, stream) -> None:
@@ -293,8 +296,11 @@ class Pending:
 
     def __init__(self, outs: dict, info: torch.Tensor, pairs: int, done=None):
         self.outs, self.info, self.pairs, self.done = outs, info, pairs, done
+        self._result = None
 
     def wait(self) -> Dict[str, torch.Tensor]:
+        if self._result is not None:    # idempotent
+            return self._result
         outs = self.outs
         if self.done is not None:   # side-stream path: the host waits for gather + unpack + the copy of the host block ONLY; the compute stream is ordered behind them
             self.done.synchronize()
@@ -308,4 +314,5 @@ class Pending:
         outs["scores"] = [row[:c] for row, c in zip(mscores.unbind(0), counts)]
         if self.pairs == 1:
             outs["stop"] = int(host[0][0])
+        self._result = outs
         return outs

@@ -413,6 +413,48 @@ def main():
         finally:
             model.set_option("tail_timing", 0, dev)
 
+    def power_probe(seconds=1.6, settle=0.6):
+        # the board's power sensor (hwmon of this GPU's PCI device) sampled while the SAME step loop runs: what the chip draws under this workload, against its
+        # cap — the quantity that bounds the two big kernels — and the pairs per joule that follow.  Outside the timed region; never fatal.
+        try:
+            import ctypes as C
+            import glob
+            import threading
+            hip = C.CDLL("libamdhip64.so")
+            buf = C.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(dev.index or 0)) != 0:
+                return None
+            hw = glob.glob(f"/sys/bus/pci/devices/{buf.value.decode().lower()}/hwmon/hwmon*")
+            if not hw:
+                return None
+            rd = lambda name: int(open(f"{hw[0]}/{name}").read())
+            cap = rd("power1_cap") / 1e6
+            samples, stop = [], threading.Event()
+            def sampler():
+                t0 = time.perf_counter()
+                while not stop.is_set():
+                    samples.append((time.perf_counter() - t0, rd("power1_input") / 1e6, rd("freq1_input") / 1e6))
+                    time.sleep(0.05)
+            th = threading.Thread(target=sampler, daemon=True); th.start()
+            t0 = time.perf_counter(); steps_done = 0; t_settled = None; steps_settled = 0
+            while time.perf_counter() - t0 < seconds:
+                step(); steps_done += 1
+                if t_settled is None and time.perf_counter() - t0 >= settle:
+                    torch.cuda.synchronize(dev); t_settled = time.perf_counter(); steps_settled = steps_done
+            drain(); torch.cuda.synchronize(dev)
+            t1 = time.perf_counter(); stop.set(); th.join(timeout=1.0)
+            late = [(w, f) for (t, w, f) in samples if t >= settle]
+            if not late or t_settled is None or steps_done == steps_settled:
+                return None
+            watts = float(np.median([w for w, _ in late])); mhz = float(np.median([f for _, f in late]))
+            rate = B * (steps_done - steps_settled) / (t1 - t_settled)
+            return {"board_power_w_median": round(watts, 1), "board_power_cap_w": cap, "sclk_mhz_median": round(mhz, 1), "pairs_per_s_during_probe": round(rate, 1),
+                    "pairs_per_joule": round(rate / watts, 3), "samples": len(late),
+                    "what": f"hwmon power1_input / freq1_input of this GPU sampled every 50 ms while the benchmark's own step loop ran for {seconds} s (first {settle} s discarded), after the timed region"}
+        except Exception as exc:
+            return {"error": repr(exc)[:200]}
+
+    power = power_probe() if (rank == 0 and world == 1 and not args.no_calibration) else None
     kernel_clock = tail_clock_mhz() if (rank == 0 and not args.no_calibration and args.precision == "f16x3" and not adaptive) else None   # (every tile live: no stale stamps)
     rccl = None
     sync_value = None
@@ -583,6 +625,7 @@ def main():
             "effective_mfma_clock_mhz": sustained_mhz, "sustained_dense_bf16_tflops": sustained_tflops,
             # the board's power limit is what bounds the two big kernels: the clock the fused tail actually ran at inside a forward, of 2 400 MHz nominal
             "shader_clock_mhz_inside_tail_kernel": kernel_clock,
+            "power": power,
             "matches_per_pair": float((out["matches0"].cpu().numpy() > -1).sum(axis=1).mean()) if "matches0" in out else None,   # (one copy: no framework kernels behind the timed region either)
             "value_synchronous_forward": sync_value,   # pairs/s with model(data) per step (host sync inside every forward), N = 1 only
             "rccl": rccl,

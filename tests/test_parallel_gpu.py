@@ -231,6 +231,8 @@ def test_bench_default_is_config_2_and_reports_the_gather_probe():
     assert d["parity"]["pairs"] == 4 and d["parity"]["index_mismatches"] == 0
     assert d["step_output"] == {"matches": "list[32] of int64", "matches0": "int64", "matches1": "int64", "matching_scores0": "float32", "matching_scores1": "float32",
                                 "prune0": "float32", "prune1": "float32", "scores": "list[32] of float32", "stop": "int64"}, d["step_output"]   # same keys / dtypes as at N > 1
+    pw = d["power"]    # the board's power sensor under the same loop (None where the box exposes no hwmon): the cap is what bounds the big kernels
+    assert pw is None or ("error" not in pw and 200 < pw["board_power_w_median"] <= pw["board_power_cap_w"] * 1.02 and pw["pairs_per_joule"] > 0), pw
     g = d["gather_probe_one_gpu"]
     assert "error" not in g, g
     assert g["matches_equal_plain_loop"] is True and g["ms_per_step_with_world1_gather"] > 0

@@ -149,3 +149,27 @@ def test_randomised_soak_of_the_gather_and_sharded_paths():
     p = subprocess.run([sys.executable, str(root / "tools" / "stress_adaptive_paths.py"), "14", "7"], capture_output=True, text=True, timeout=900, cwd=str(root))
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1500:]
     assert "all bit-identical" in p.stdout
+
+
+@pytest.mark.parametrize("B,n,m,adaptive", [(1, 1, 8192, False), (1, 8192, 3, False), (2, 4100, 130, True), (96, 17, 40, False), (3, 129, 127, True)])
+def test_extreme_aspect_shapes_against_the_oracle(B, n, m, adaptive):
+    """Corners of the envelope the fixtures do not hold: one keypoint against 8 192, 8 192 against three (single-row / single-tile segments next to 64-tile ones),
+    a segment one row past a tile boundary with pruning, many tiny pairs per batch, lengths straddling 128."""
+    require_gpu()
+    torch.set_num_threads(8)
+    recipe = "C" if adaptive else "A"
+    sd = synth.make_state_dict(2, recipe=recipe)
+    data = synth.make_batch(300 + n + m, B, n, m)
+    conf_kw = dict(pruning_min_kpts=64) if adaptive else dict(depth_confidence=-1, width_confidence=-1, filter_threshold=0.0 if min(n, m) < 8 else 0.1)
+    ref = O.forward(sd, O.make_conf(**conf_kw), data, backend="torch")
+    model = gpu_util.make_model(sd, "f16x3", **conf_kw)
+    out = model(gpu_util.to_torch(data))
+    gold = {k: np.asarray(ref[k]) for k in ("matches0", "matches1", "matching_scores0", "matching_scores1")}
+    case = {"conf": conf_kw, "recipe": recipe, "wseed": 2, "dseed": 300 + n + m, "n": n, "m": m, "B": B, "dim": 256, **({"prune_th": 64} if adaptive else {})}
+    flips = assert_parity_with_explained_flips(out, gold, case, sd, data, score_tol=SCORE_TOL)
+    assert sum(flips) <= 2, flips
+    stop = out["stop"] if torch.is_tensor(out["stop"]) else torch.tensor([out["stop"]])
+    np.testing.assert_array_equal(stop.cpu().numpy().reshape(-1), np.asarray(ref["stop"]).reshape(-1))
+    if adaptive:
+        np.testing.assert_array_equal(out["prune0"].cpu().numpy(), np.asarray(ref["prune0"]))
+        np.testing.assert_array_equal(out["prune1"].cpu().numpy(), np.asarray(ref["prune1"]))

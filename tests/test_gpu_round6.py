@@ -173,3 +173,37 @@ def test_extreme_aspect_shapes_against_the_oracle(B, n, m, adaptive):
     if adaptive:
         np.testing.assert_array_equal(out["prune0"].cpu().numpy(), np.asarray(ref["prune0"]))
         np.testing.assert_array_equal(out["prune1"].cpu().numpy(), np.asarray(ref["prune1"]))
+
+
+def test_input_dtype_and_layout_variants_give_the_same_result():
+    """The class accepts what the reference accepts (ref :483-506 takes any float tensors): float64 or non-contiguous inputs, an image_size given as a list, int64
+    num_keypoints — all normalised to the engine's fp32 / int32 contiguous buffers on the way in; fp16 inputs match a forward on their fp32-widened values."""
+    require_gpu()
+    sd = synth.make_state_dict(0, recipe="A")
+    model = gpu_util.make_model(sd, "f16x3", depth_confidence=-1, width_confidence=-1)
+    data = gpu_util.to_torch(synth.make_batch(9, 2, 300, 280))
+    base = model(data)
+    keys = ("matches0", "matches1", "matching_scores0", "matching_scores1")
+    same = lambda a: all(torch.equal(a[k], base[k]) for k in keys)
+    f64 = {k: {kk: vv.double() for kk, vv in v.items()} for k, v in data.items()}
+    assert same(model(f64))
+    strided = {k: dict(v) for k, v in data.items()}
+    for k in strided:   # [B, N, D] view of a [B, D, N] buffer: same values, permuted strides
+        strided[k]["descriptors"] = data[k]["descriptors"].transpose(1, 2).contiguous().transpose(1, 2)
+        assert not strided[k]["descriptors"].is_contiguous()
+    assert same(model(strided))
+    lists = {k: dict(v) for k, v in data.items()}
+    for k in lists:
+        lists[k]["image_size"] = data[k]["image_size"][0].tolist()          # one [w, h] for the whole batch (the batch shares it in this fixture)
+    assert torch.equal(data["image0"]["image_size"][0], data["image0"]["image_size"][1])
+    assert same(model(lists))
+    counted = {k: dict(v) for k, v in data.items()}
+    counted["image0"]["num_keypoints"] = torch.tensor([300, 300], dtype=torch.int64)      # on the CPU, int64: full counts == no counts
+    counted["image1"]["num_keypoints"] = [280, 280]
+    assert same(model(counted))
+    half = {k: {kk: (vv.half() if kk == "descriptors" else vv) for kk, vv in v.items()} for k, v in data.items()}
+    widened = {k: {kk: (vv.half().float() if kk == "descriptors" else vv) for kk, vv in v.items()} for k, v in data.items()}
+    a, b = model(half), model(widened)
+    assert all(torch.equal(a[k], b[k]) for k in keys)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model({k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in data.items()})

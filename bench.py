@@ -316,7 +316,15 @@ def main():
     sd = synthetic.make_state_dict(cfg["wseed"], recipe=args.recipe, input_dim=dim)
     model = LightGlue(features=None, precision=args.precision, attention_precision=args.attention, **conf_kw).eval()
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    if os.environ.get("LG_BENCH_ABLATION") == "1":   # timing ablations (variant libraries that compute garbage on purpose): no range guard, no parity block
+        model.check_finite = False
     data_np = synthetic.make_batch(1 + rank * B, B, n, m, dim, **batch_kwargs(args.recipe))
+    if os.environ.get("LG_BENCH_PERIODIC"):   # timing ablations only: every 64-key tile of an image holds the SAME keypoints, so a variant that races on K / V tiles still computes valid values
+        per = int(os.environ["LG_BENCH_PERIODIC"])
+        for img in ("image0", "image1"):
+            for key in ("keypoints", "descriptors"):
+                a = data_np[img][key]
+                data_np[img][key] = np.ascontiguousarray(np.tile(a[:, :per], (1, a.shape[1] // per) + (1,) * (a.ndim - 2)))
     data = {k: {kk: torch.from_numpy(vv).to(dev) for kk, vv in v.items()} for k, v in data_np.items()}
     model.reserve(B, n, m, dev)
     for kv in os.environ.get("LG_BENCH_OPTS", "").split():   # A/B of engine options in one box, e.g. LG_BENCH_OPTS="tail_row_tiles=2 attn_rows=64"
@@ -638,7 +646,7 @@ def main():
         # match-index parity of the batch that was just timed (rank 0's pairs): against the reference's own fixture for the
         # first 4 pairs and against the oracle on the pairs the CPU leg runs anyway
         default_weights = args.precision in ("f16x3", "fp32")
-        res["parity"] = golden_parity(out, n, B, args.recipe, args.config, m) if default_weights else None
+        res["parity"] = golden_parity(out, n, B, args.recipe, args.config, m) if (default_weights and os.environ.get("LG_BENCH_ABLATION") != "1") else None
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"], res["parity_oracle"] = cpu_baseline(sd, n, m, gpu_out=out, recipe=args.recipe, conf_kw={k: v for k, v in conf_kw.items() if k != "input_dim"}, dim=dim, wseed=cfg["wseed"])
         json_out.write(json.dumps(res) + "\n")

@@ -258,6 +258,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-probe", action="store_true", help="one GPU: skip the K extra steps that measure what the (world-of-one) side-stream result gather costs a step")
     ap.add_argument("--no-pipeline", action="store_true", help="one GPU: synchronous forward per step (no deferred output assembly)")
+    ap.add_argument("--inflight", type=int, default=None, help="one GPU: whole batches in flight (lightglue_amd.InflightMatcher: one engine + one HIP stream per lane, step i on lane i %% F).  Default: 1 at the "
+                    "fixed-depth configs (2, 4: every launch fills the chip, a second lane measures -1 %% / +-0), 2 at the adaptive configs (3, 5), whose late layers cover a fraction of the chip once most pairs "
+                    "have stopped (+3 ... +11 %%, profiles/r06t_ab_inflight.log, r06u_*)")
     ap.add_argument("--no-calibration", action="store_true", help="skip the 25 ms dense-MFMA spin that measures what the box sustains (profiling runs)")
     ap.add_argument("--no-fuse-next", action="store_true", help="run the q/k/v projections as their own kernels instead of inside the previous block's tail kernel")
     ap.add_argument("--unfused", action="store_true", help="use the per-op kernels instead of the fused block tail")
@@ -335,10 +338,24 @@ def main():
     if args.unfused:
         model.set_option("fused_tail", 0, dev)
     sharded = PairShardedMatcher(model) if world > 1 else None
+    if args.inflight is None:
+        args.inflight = 2 if (adaptive and world == 1 and not args.no_pipeline) else 1
+    lanes = None
+    if args.inflight > 1 and world == 1 and not args.no_pipeline:
+        from lightglue_amd import InflightMatcher
+        lanes = InflightMatcher(model, args.inflight, dev)
+        lanes.reserve(B, n, m)
+        lane_pending = [None] * args.inflight
+        lane_next = [0]
 
     pending = [None]
 
     def step():
+        if lanes is not None:
+            # F whole batches in flight: step i runs on lane i % F (its own engine and stream); its full output dict is built when the lane is used next
+            k = lane_next[0]; lane_next[0] = (k + 1) % args.inflight
+            prev, lane_pending[k] = lane_pending[k], lanes.submit(data)
+            return prev.result() if prev is not None else None
         if sharded is not None:
             # the result gather of this step stays in flight on the side stream while the next step's forward runs;
             # every gather is waited for (and unpacked) one step later, the last one before the closing barrier
@@ -353,6 +370,13 @@ def main():
         return prev.result() if prev is not None else None
 
     def drain():
+        if lanes is not None:
+            last = None
+            for i in range(args.inflight):
+                k = (lane_next[0] + i) % args.inflight      # oldest first
+                if lane_pending[k] is not None:
+                    last, lane_pending[k] = lane_pending[k].result(), None
+            return last
         if pending[0] is not None:
             last, pending[0] = pending[0], None
             return last.wait() if sharded is not None else last.result()
@@ -591,9 +615,11 @@ def main():
                                    + f"seeded random weights (recipe {args.recipe}{', trained-model statistics' if args.recipe == 'D' else ''}), precision={args.precision}"
                                    + (" (split-f16 operands, 3 MFMAs per product, for every contraction incl. q k^T and P V; fp32 accumulate / residual / softmax)" if args.precision == "f16x3" and not args.attention else "")
                                    + (", attention_precision=fp16 (single-plane f16 attention: the fast opt-in, outside the 1e-3 bar for sharp attention)" if args.attention else ""),
-                       "pairs_per_gpu": B, "keypoints": n, "keypoints1": m, "descriptor_dim": dim, "parallelism": f"pair-sharded dp{world}",
+                       "pairs_per_gpu": B, "keypoints": n, "keypoints1": m, "descriptor_dim": dim, "parallelism": f"pair-sharded dp{world}", "batches_in_flight": (args.inflight if lanes is not None else 1),
                        "host_pipelining": ("result gather of step i overlaps the forward of step i+1" if world > 1 else
                                            "synchronous forward per step" if args.no_pipeline else
+                                           f"{args.inflight} whole batches in flight (lightglue_amd.InflightMatcher: step i on lane i % {args.inflight}, one engine + one HIP stream per lane); a step's full output dict is built when its lane is used next, all K inside the timed region; "
+                                           "event-timed launches (roofline legs) overlap the other lanes' kernels and read longer than alone" if lanes is not None else
                                            "output assembly (the forward's one host sync) of step i overlaps the forward of step i+1; all K outputs are built inside the timed region")},
             "roofline": {"bound": "mfma", "kernel": dom + (" (+ next block's q/k/v projection)" if fused_next and dom == "fused_tail" else ""), "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic_dom[0], "traffic_source": traffic_dom[1],

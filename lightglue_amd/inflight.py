@@ -5,6 +5,8 @@ layers then fill only a fraction of the chip: at BASELINE config 3 (16 pairs of 
 workgroups on a quarter of the CUs.  A second batch's early layers, issued on another HIP stream, run in that space: measured +3 … +4 % at config
 3 and +6 % at config 5 with two or three batches in flight, −1 % at config 2 and ±0 at config 4, where every launch already fills the chip
 (``tools/ab_inflight.py``, ``profiles/r06t_ab_inflight.log``).
+A stream of single pairs (B = 1 per call) gains most — x2.5 ... x3.5 with four lanes at N = 512 / 1 024 (``profiles/r06v_ab_inflight_b1.log``); beyond four lanes the runtime's hardware
+queues are shared and the rate falls again.
 
 How.  ``InflightMatcher(model, depth)`` holds ``depth`` LANES: a lane = one ``LightGlue`` instance (its own engine, i.e. its own workspace — the
 first lane is ``model`` itself, the others are deep copies made at construction) + one HIP stream.  ``submit(data)`` deals batches to the lanes round

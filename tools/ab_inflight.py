@@ -60,7 +60,7 @@ def run(parts, streams, steps, warmup, dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--configs", default="2,3,5")
+    ap.add_argument("--configs", default="2,3,5", help="BASELINE config numbers; or shapes as B:N[:adaptive], e.g. 1:512 or 1:2048:a (config 1 and the B = 1 serving case)")
     ap.add_argument("--inflight", default="1,2,3")
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=6)
@@ -68,8 +68,13 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    for c in [int(x) for x in args.configs.split(",")]:
-        cfg = bench.CONFIGS[c]
+    for c in args.configs.split(","):
+        if ":" in c:
+            f = c.split(":")
+            ad = len(f) > 2 and f[2].startswith("a")
+            cfg = dict(pairs=int(f[0]), n=int(f[1]), m=int(f[1]), dim=256, recipe="C" if ad else "A", wseed=0, adaptive=ad)
+        else:
+            c = int(c); cfg = bench.CONFIGS[c]
         sd = synthetic.make_state_dict(cfg["wseed"], input_dim=cfg["dim"], recipe=cfg["recipe"])
         data_np = synthetic.make_batch(1, cfg["pairs"], cfg["n"], cfg["m"], dim=cfg["dim"])
         ref = None

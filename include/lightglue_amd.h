@@ -180,6 +180,8 @@ int lg_unpack_wire(const lg_unpack_io* io, void* hip_stream);
  *                     the shape
  *   "adapt_gather" 1  adaptive width: the SelfBlock projection behind a pruning step gathers its rows through the decide kernel's index map and writes
  *                     them compacted into a second buffer set (no compaction launch; bit-identical to 0 = the in-place compaction kernel)
+ *   "sim_planes"   1  precision f16x3: the final projection stores its rows as f16 hi / lo planes and the similarity matrix is multiplied straight from an LDS-DMA
+ *                     ring (lg_sim.hip); 0 = fp32 rows + the generic GEMM that splits them per K stage (bit-identical)
  *   "attn_dma"     1  single-plane 16-bit attention, 32 rows per wave: K / V^T tiles reach LDS by DMA (two buffers, one barrier per
  *                     tile, 4 waves per SIMD); 0 = the register-staged kernel (bit-identical).  The split attention is always DMA
  *   "tail_row_tiles" 0  16-row tiles per fused-tail workgroup: 4 (64 rows) | 2 | 1, 0 = by grid fill (small grids take the

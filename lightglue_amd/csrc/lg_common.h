@@ -148,6 +148,15 @@ __device__ __forceinline__ void lds_dma16(const void* gptr, void* lds) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(gptr) : "memory", "m0");
 }
 
+// the same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset (global_load_lds_dwordx4 v, s[..]): no 64-bit VALU address per request
+__device__ __forceinline__ void lds_dma16_s(const void* sbase, uint32_t voff, void* lds) {
+    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds);
+    const uint64_t b = (uint64_t)(uintptr_t)sbase;
+    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)b), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    const uint64_t sb = ((uint64_t)bhi << 32) | blo;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(voff), "s"(sb) : "memory", "m0");
+}
+
 // ---- weight fragments by buffer load: the fragment-packed weight arrays are read as base descriptor (SGPRs) + one per-lane VGPR offset (16 lane,
 // constant for the kernel) + a SCALAR byte offset per fragment.  As plain global loads hipcc built a 64-bit VGPR address per load (v_lshl_add_u64 +
 // v_add_co / v_addc pairs and an s_nop in front of each load: 12 VALU + 7 s_nop per k-chunk of the tail's phase A, round-4 ISA), all of it in the gap

@@ -126,6 +126,8 @@ struct lg_engine {
     // a pruning step reads rows from one set and writes the compacted rows to the other (lg_proj.hip proj_gather_kernel) —, and which set each pair's rows are in
     float *X2 = nullptr, *COS2 = nullptr, *SIN2 = nullptr; int* XSEL = nullptr;
     bool adapt_gather = true;
+    // split-f16 precision: the final projection stores f16 hi / lo planes and the similarity matrix is sim_planes_kernel (lg_sim.hip); 0 = fp32 rows + the generic sim_kernel (bit-identical)
+    bool sim_planes = true;
     int debug_stop = -1;
     // ---- per-kernel-class HIP-event timing (bench.py roofline leg)
     bool profiling = false, prof_open = false;
@@ -669,6 +671,7 @@ int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
     if (std::strcmp(key, "fused_prep") == 0) { e->fused_prep = value != 0; return LG_OK; }
     if (std::strcmp(key, "attn_dma") == 0) { e->attn_dma = value != 0; return LG_OK; }
     if (std::strcmp(key, "adapt_gather") == 0) { e->adapt_gather = value != 0; return LG_OK; }
+    if (std::strcmp(key, "sim_planes") == 0) { e->sim_planes = value != 0; return LG_OK; }
     if (std::strcmp(key, "attn_rows") == 0) { if (value != 16 && value != 32 && value != 64) return fail(LG_ERR_INVALID, "attn_rows must be 16, 32 or 64"); e->attn_rows = value; e->attn_auto_rows = false; return LG_OK; }
     if (std::strcmp(key, "tail_row_tiles") == 0) { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(LG_ERR_INVALID, "tail_row_tiles must be 0 (automatic), 1, 2 or 4"); e->tail_row_tiles = value; return LG_OK; }
     if (std::strcmp(key, "profile_only") == 0) { e->prof_only = value; return LG_OK; }   // kernel class index, -1 = all classes
@@ -943,6 +946,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
     auto make_final = [&](const RowSpace& rs, int layer, bool per_pair) {   // final projection (ref :289-291: / d**0.25), lg_proj.hip / fused into the last tail
         FinalArgs f{};
         f.rs = rs; f.X = per_pair ? e->X : Xs[xcur]; f.R = R; f.out = e->MD; f.scale = 0.25f;
+        f.planes = (prec == PREC_F16X3 && e->sim_planes) ? 1 : 0;
         if (per_pair) { f.X2 = e->X2; f.xsel = e->XSEL; }    // XSEL stays 0 unless a gather projection ran
         f.W = e->w_final_p + (per_pair ? 0 : (size_t)layer * e->final_layer_bytes); f.bias = e->b_final + (per_pair ? 0 : (size_t)layer * D);
         f.layer_of_pair = per_pair ? e->FINAL_LAYER : nullptr; f.w_layer_bytes = (long long)e->final_layer_bytes;
@@ -1120,9 +1124,14 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
             HIPCHK(launch_final_proj(prec, make_final(rs_all, 0, true), s));
             TRY(prof_end(e, s));
         }
-        SimArgs sm{rs_all, e->MD, D, D, e->SIM};
         TRY(prof_begin(e, PC_SIM, s));
-        HIPCHK(launch_sim(prec, sm, s));
+        if (prec == PREC_F16X3 && e->sim_planes) {
+            SimPlanesArgs sp{rs_all, reinterpret_cast<const f16_t*>(e->MD), (long long)R * 256, D, e->SIM};
+            HIPCHK(launch_sim_planes(sp, s));
+        } else {
+            SimArgs sm{rs_all, e->MD, D, D, e->SIM};
+            HIPCHK(launch_sim(prec, sm, s));
+        }
         TRY(prof_end(e, s));
         AssignArgs as{};
         as.rs = rs_all; as.sim = e->SIM; as.ls = e->LS; as.lse_r = e->LSE_R; as.lse_c = e->LSE_C; as.max0 = e->MAX0; as.arg0 = e->ARG0;

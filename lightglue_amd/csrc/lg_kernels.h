@@ -35,6 +35,14 @@ struct SimArgs {
     float* sim;   // [B][cap0][cap1]
 };
 hipError_t launch_sim(int prec, const SimArgs& a, hipStream_t s);
+// the same product for the split-f16 precision on operands that arrive as f16 planes (lg_sim.hip): md = [2 planes][R][256] f16 (hi, then lo at + plane
+// elements), written by the final projection (FinalArgs::planes)
+struct SimPlanesArgs {
+    RowSpace rs;
+    const f16_t* md; long long plane; int K;
+    float* sim;   // [B][cap0][cap1]
+};
+hipError_t launch_sim_planes(const SimPlanesArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- attention input projections (lg_proj.hip)
 // q/k/v (self, rotary on q,k) or qk/v (cross) from the residual stream; weights fragment-packed like TailArgs
@@ -74,6 +82,7 @@ struct FinalArgs {
     const int* layer_of_pair; long long w_layer_bytes;   // optional per-pair layer select; nullptr: W / bias point at the layer to use
     float* out; float scale;                         // [R][256] fp32
     int R;
+    int planes;                                      // split-f16 precision only: != 0 -> `out` receives f16 hi / lo planes [2][R][256] (same bytes) for launch_sim_planes instead of fp32 rows
     const float* X2; const int* xsel;                // optional: pair p's rows live in X2 when xsel[p] != 0 (the gather path flips buffers per pruning layer; a stopped pair stays where it was)
 };
 hipError_t launch_final_proj(int prec, const FinalArgs& a, hipStream_t s);

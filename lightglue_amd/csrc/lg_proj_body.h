@@ -359,6 +359,26 @@ __device__ __forceinline__ void final_compute(const FinalArgs& a, const TileLoc&
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    if constexpr (NPART == 2) {
+        if (a.planes) {   // split-f16: the rows leave as the hi / lo f16 planes the similarity kernel multiplies (lg_sim.hip) — the same split, of the same fp32 values, that
+            // sim_kernel used to redo per K stage in every workgroup; [2][R][256] f16 = the bytes of the fp32 rows.  4 consecutive columns per lane and tile: 8-byte stores
+            f16_t* md = reinterpret_cast<f16_t*>(a.out);
+            const long long plane = (long long)a.R * 256;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f16_t* dst = md + (t.grow0 + pj_row<MT>(mt, lr)) * 256LL + 32 * w + 4 * g;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f32x4 v = (acc[mt][j] + b4[j]) * a.scale;
+                    uint32_t h01, l01, h23, l23;
+                    split2_f16(v[0], v[1], h01, l01); split2_f16(v[2], v[3], h23, l23);
+                    *reinterpret_cast<u32x2*>(dst + 16 * j) = u32x2{h01, h23};
+                    *reinterpret_cast<u32x2*>(dst + 16 * j + plane) = u32x2{l01, l23};
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         float* dst = a.out + (t.grow0 + pj_row<MT>(mt, lr)) * 256LL + 32 * w + 4 * g;

@@ -207,3 +207,47 @@ def test_input_dtype_and_layout_variants_give_the_same_result():
     assert all(torch.equal(a[k], b[k]) for k in keys)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model({k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in data.items()})
+
+
+def test_similarity_on_planes_equals_the_generic_kernel():
+    """Split-f16 precision: the final projection stores f16 hi / lo planes and `sim_planes_kernel` (lg_sim.hip) multiplies them straight from an LDS-DMA ring
+    (engine option sim_planes, default on) — the same split of the same fp32 values and the same MFMA sequence per output element as the generic
+    `sim_kernel`, which splits fp32 rows per K stage.  Every output incl. the full log-assignment matrix must be BIT-identical with the option off: fixed depth
+    (the last tail runs the final projection) and adaptive (its own launch, per-pair layer select), tile-edge and sub-tile sizes, more than one 256-row chunk
+    of image-1 rows, ragged counts with an empty image, NaN-poisoned padding."""
+    require_gpu()
+    cases = [("A", dict(depth_confidence=-1, width_confidence=-1), (3, 2, 1024, 1024), {}),
+             ("A", dict(depth_confidence=-1, width_confidence=-1), (4, 3, 130, 700), dict(log_assignment=True)),
+             ("A", dict(depth_confidence=-1, width_confidence=-1), (5, 2, 5, 3), dict(log_assignment=True)),
+             ("A", dict(depth_confidence=-1, width_confidence=-1), (6, 1, 257, 65), {}),
+             ("A", dict(depth_confidence=-1, width_confidence=-1), (7, 1, 64, 1537), {}),
+             ("A", dict(depth_confidence=-1, width_confidence=-1), (8, 3, 300, 520), dict(nums=([300, 0, 129], [520, 64, 1]), poison=True, log_assignment=True)),
+             ("C", dict(pruning_min_kpts=64), (17, 3, 300, 333), dict(log_assignment=True)),
+             ("C", dict(), (201, 2, 2048, 2048), {}),
+             ("D", dict(depth_confidence=-1, width_confidence=-1), (61, 2, 640, 512), dict(recipe_d_data=True))]
+    for recipe, kw, (seed, B, n, m), opt in cases:
+        sd = synth.make_state_dict(0, recipe=recipe)
+        batch = synth.make_batch(seed, B, n, m, **(synth.RECIPE_D_DATA if opt.get("recipe_d_data") else {}))
+        if opt.get("poison"):
+            for img, nums in zip(("image0", "image1"), opt["nums"]):
+                for b, c in enumerate(nums):
+                    batch[img]["keypoints"][b, c:] = np.nan
+                    batch[img]["descriptors"][b, c:] = np.nan
+        data = gpu_util.to_torch(batch)
+        if "nums" in opt:
+            data["image0"]["num_keypoints"] = torch.as_tensor(opt["nums"][0], dtype=torch.int32, device="cuda")
+            data["image1"]["num_keypoints"] = torch.as_tensor(opt["nums"][1], dtype=torch.int32, device="cuda")
+        model = gpu_util.make_model(sd, "f16x3", **kw)
+        model.check_finite = False
+        model.return_log_assignment = bool(opt.get("log_assignment"))
+        on = model(data)
+        model.set_option("sim_planes", 0)
+        off = model(data)
+        model.set_option("sim_planes", 1)
+        again = model(data)
+        keys = ("matches0", "matches1", "matching_scores0", "matching_scores1") + (("log_assignment",) if opt.get("log_assignment") else ())
+        for key in keys:
+            assert torch.equal(on[key], off[key]), (recipe, key, n, m)
+            assert torch.equal(on[key], again[key]), (recipe, key, "second forward")
+        assert torch.equal(torch.as_tensor(on["stop"]), torch.as_tensor(off["stop"]))
+        assert (on["matches0"] >= 0).any() or n < 8, "the case should produce matches"

@@ -9,7 +9,7 @@ ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 mkdir -p "$ROOT/build_variants/obj_$NAME"
 cd "${LG_VARIANT_SRC:-$ROOT/lightglue_amd/csrc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form -fno-slp-vectorize"
-for f in lg_gemm lg_tail lg_proj lg_attention lg_pointwise lg_adaptive lg_assign lg_superpoint lg_sp_encoder lg_engine; do
+for f in lg_gemm lg_sim lg_tail lg_proj lg_attention lg_pointwise lg_adaptive lg_assign lg_superpoint lg_sp_encoder lg_engine; do
   hipcc $FLAGS "$@" -c $f.hip -o "$ROOT/build_variants/obj_$NAME/$f.o" &
 done
 wait

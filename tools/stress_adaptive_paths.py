@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised soak of the round-6 paths on a GPU: for seeded random shapes / thresholds / ragged counts / recipes, (1) the gather projection (adapt_gather = 1, the
 product path) against the in-place compaction kernel (adapt_gather = 0) — every output bit for bit —, (2) PairShardedMatcher's world-of-one step (engine-packed wire
-row -> lg_unpack_wire -> dict) against LightGlue.forward — same keys, dtypes, values, ragged lists —, (3) the same forward twice (buffer sets flip inside a forward).
+row -> lg_unpack_wire -> dict) against LightGlue.forward — same keys, dtypes, values, ragged lists —, (3) the same forward twice (buffer sets flip inside a forward), (4) the similarity matrix on f16 planes (sim_planes = 1) against the generic kernel.
 usage: python tools/stress_adaptive_paths.py [cases=60] [seed=0]"""
 import sys
 from pathlib import Path
@@ -43,7 +43,12 @@ for c in range(cases):
     sharded = PairShardedMatcher(model)(data)
     model.set_option("adapt_gather", 0)
     off = model(data)
+    model.set_option("adapt_gather", 1)
+    model.set_option("sim_planes", 0)        # (4) split-f16: the similarity matrix on f16 planes (lg_sim.hip, the product path) against the generic fp32-row kernel
+    generic = model(data)
     msgs = []
+    for k in KEYS:
+        if not torch.equal(on[k], generic[k]): msgs.append(f"sim on planes != generic sim kernel: {k}")
     for k in KEYS:
         if not torch.equal(on[k], off[k]): msgs.append(f"gather != compaction: {k}")
         if not torch.equal(on[k], again[k]): msgs.append(f"second forward differs: {k}")

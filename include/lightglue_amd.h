@@ -182,6 +182,7 @@ int lg_unpack_wire(const lg_unpack_io* io, void* hip_stream);
  *                     them compacted into a second buffer set (no compaction launch; bit-identical to 0 = the in-place compaction kernel)
  *   "sim_planes"   1  precision f16x3: the final projection stores its rows as f16 hi / lo planes and the similarity matrix is multiplied straight from an LDS-DMA
  *                     ring (lg_sim.hip); 0 = fp32 rows + the generic GEMM that splits them per K stage (bit-identical)
+ *   "sim_chunk"    0  image-1 rows per workgroup of that kernel: 0 = by grid fill (512 for batches that fill the chip, down to 64 for single pairs), or a multiple of 64
  *   "attn_dma"     1  single-plane 16-bit attention, 32 rows per wave: K / V^T tiles reach LDS by DMA (two buffers, one barrier per
  *                     tile, 4 waves per SIMD); 0 = the register-staged kernel (bit-identical).  The split attention is always DMA
  *   "tail_row_tiles" 0  16-row tiles per fused-tail workgroup: 4 (64 rows) | 2 | 1, 0 = by grid fill (small grids take the

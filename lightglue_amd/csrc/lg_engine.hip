@@ -128,6 +128,7 @@ struct lg_engine {
     bool adapt_gather = true;
     // split-f16 precision: the final projection stores f16 hi / lo planes and the similarity matrix is sim_planes_kernel (lg_sim.hip); 0 = fp32 rows + the generic sim_kernel (bit-identical)
     bool sim_planes = true;
+    int sim_chunk = 0;      // image-1 rows per sim_planes workgroup, 0 = by grid fill (option "sim_chunk": tests / A-B; bit-identical)
     int debug_stop = -1;
     // ---- per-kernel-class HIP-event timing (bench.py roofline leg)
     bool profiling = false, prof_open = false;
@@ -672,6 +673,7 @@ int lg_engine_set_option(lg_engine* e, const char* key, int32_t value) {
     if (std::strcmp(key, "attn_dma") == 0) { e->attn_dma = value != 0; return LG_OK; }
     if (std::strcmp(key, "adapt_gather") == 0) { e->adapt_gather = value != 0; return LG_OK; }
     if (std::strcmp(key, "sim_planes") == 0) { e->sim_planes = value != 0; return LG_OK; }
+    if (std::strcmp(key, "sim_chunk") == 0) { if (value < 0 || value % 64) return fail(LG_ERR_INVALID, "sim_chunk: 0 or a multiple of 64"); e->sim_chunk = value; return LG_OK; }
     if (std::strcmp(key, "attn_rows") == 0) { if (value != 16 && value != 32 && value != 64) return fail(LG_ERR_INVALID, "attn_rows must be 16, 32 or 64"); e->attn_rows = value; e->attn_auto_rows = false; return LG_OK; }
     if (std::strcmp(key, "tail_row_tiles") == 0) { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(LG_ERR_INVALID, "tail_row_tiles must be 0 (automatic), 1, 2 or 4"); e->tail_row_tiles = value; return LG_OK; }
     if (std::strcmp(key, "profile_only") == 0) { e->prof_only = value; return LG_OK; }   // kernel class index, -1 = all classes
@@ -1126,7 +1128,7 @@ int lg_engine_forward(lg_engine* e, const lg_forward_io* io, void* hip_stream) {
         }
         TRY(prof_begin(e, PC_SIM, s));
         if (prec == PREC_F16X3 && e->sim_planes) {
-            SimPlanesArgs sp{rs_all, reinterpret_cast<const f16_t*>(e->MD), (long long)R * 256, D, e->SIM};
+            SimPlanesArgs sp{rs_all, reinterpret_cast<const f16_t*>(e->MD), (long long)R * 256, D, e->SIM, e->sim_chunk};
             HIPCHK(launch_sim_planes(sp, s));
         } else {
             SimArgs sm{rs_all, e->MD, D, D, e->SIM};

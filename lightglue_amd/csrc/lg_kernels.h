@@ -41,6 +41,7 @@ struct SimPlanesArgs {
     RowSpace rs;
     const f16_t* md; long long plane; int K;
     float* sim;   // [B][cap0][cap1]
+    int chunk;    // image-1 rows per workgroup (multiple of 64); <= 0: chosen by grid fill
 };
 hipError_t launch_sim_planes(const SimPlanesArgs& a, hipStream_t s);
 

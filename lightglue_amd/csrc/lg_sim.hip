@@ -19,11 +19,12 @@
 
 namespace lg {
 
-constexpr int SBM = 128, SCHUNK = 512, STHREADS = 512, SHALF = 2 * 32 * 512;   // rows per strip, image-1 rows per workgroup, threads, bytes of one half buffer
+constexpr int SBM = 128, STHREADS = 512, SHALF = 2 * 32 * 512;   // rows per strip, image-1 rows per workgroup, threads, bytes of one half buffer
 
 __global__ __launch_bounds__(STHREADS, 4) void sim_planes_kernel(SimPlanesArgs a) {
     typedef TagF16 Tag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int SCHUNK = a.chunk;                                  // image-1 rows per workgroup: 512 when the grid fills the chip, less for small batches (launch_sim_planes)
     const int strips = a.rs.cap0 / SBM, chunks = (a.rs.cap1 + SCHUNK - 1) / SCHUNK, per_pair = strips * chunks;
     // XCD-aware order (xcd_remap hands every XCD a contiguous range of virtual ids): a pair's workgroups run back to back on ONE XCD, whose L2 then holds the
     // pair's two descriptor sets for all of them
@@ -129,9 +130,17 @@ __global__ __launch_bounds__(STHREADS, 4) void sim_planes_kernel(SimPlanesArgs a
     (void)ntile;
 }
 
-hipError_t launch_sim_planes(const SimPlanesArgs& a, hipStream_t s) {
+hipError_t launch_sim_planes(const SimPlanesArgs& a0, hipStream_t s) {
+    SimPlanesArgs a = a0;
     if (a.rs.cap0 % SBM || a.rs.cap1 % 64 || a.K != 256 || !a.md || a.plane <= 0) return hipErrorInvalidValue;
-    const int strips = a.rs.cap0 / SBM, chunks = (a.rs.cap1 + SCHUNK - 1) / SCHUNK;
+    // image-1 rows per workgroup: the longest walk (fewest operand reloads) that still gives the chip two workgroups per CU; single pairs and small batches take shorter
+    // walks instead of leaving CUs idle (B = 1, N = 512: 4 workgroups of 512 rows would be 4 CUs busy).  The arithmetic per output element does not depend on it.
+    const int strips = a.rs.cap0 / SBM;
+    int chunk = 512;
+    while (chunk > 64 && (long long)strips * ((a.rs.cap1 + chunk - 1) / chunk) * a.rs.B < 512) chunk >>= 1;
+    if (a.chunk <= 0) a.chunk = chunk;
+    if (a.chunk % 64) return hipErrorInvalidValue;
+    const int chunks = (a.rs.cap1 + a.chunk - 1) / a.chunk;
     hipLaunchKernelGGL(sim_planes_kernel, dim3(strips * chunks * a.rs.B), dim3(STHREADS), 2 * SHALF, s, a);
     return hipGetLastError();
 }

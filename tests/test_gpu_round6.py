@@ -245,6 +245,12 @@ def test_similarity_on_planes_equals_the_generic_kernel():
         off = model(data)
         model.set_option("sim_planes", 1)
         again = model(data)
+        for chunk in (64, 256, 512):                     # image-1 rows per workgroup (default: by grid fill): the arithmetic per element does not depend on it
+            model.set_option("sim_chunk", chunk)
+            forced = model(data)
+            for key in ("matching_scores0", "matching_scores1", "matches0"):
+                assert torch.equal(on[key], forced[key]), (recipe, key, n, m, chunk)
+        model.set_option("sim_chunk", 0)
         keys = ("matches0", "matches1", "matching_scores0", "matching_scores1") + (("log_assignment",) if opt.get("log_assignment") else ())
         for key in keys:
             assert torch.equal(on[key], off[key]), (recipe, key, n, m)

@@ -19,7 +19,7 @@ import torch
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-from lightglue_amd import LightGlue, synthetic  # noqa: E402
+from lightglue_amd import InflightMatcher, LightGlue, synthetic  # noqa: E402
 
 torch.set_grad_enabled(False)
 
@@ -37,6 +37,22 @@ def measure(matcher, data, r=100):
         torch.cuda.synchronize()
         times[rep] = start.elapsed_time(end)
     return {"mean": float(times.mean()), "std": float(times.std())}
+
+
+def measure_lanes(matcher, data, lanes: int, r=100):
+    """Throughput form with `lanes` forwards in flight (lightglue_amd.InflightMatcher: one engine + one HIP stream per lane; every result is the full
+    output dict of forward): wall time per forward in ms over r forwards.  The reference's synchronous forward has no counterpart; a stream of single
+    pairs is where it pays (a B = 1 forward fills a fraction of the chip)."""
+    import time
+    fly = InflightMatcher(matcher, lanes)
+    for _ in fly.map(data for _ in range(10)):
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in fly.map(data for _ in range(r)):
+        pass
+    torch.cuda.synchronize()
+    return {"mean": (time.perf_counter() - t0) / r * 1e3, "std": 0.0}
 
 
 def make_pair(kind: str, batch: int, n: int, device):
@@ -72,6 +88,8 @@ def main():
     ap.add_argument("--num_keypoints", nargs="+", type=int, default=[256, 512, 1024, 2048, 4096])
     ap.add_argument("--batch", type=int, default=1, help="image pairs per forward (extension; the reference benchmark is B = 1)")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16", "fp16", "fp32"])
+    ap.add_argument("--lanes", type=int, default=1, help="forwards in flight (extension, lightglue_amd.InflightMatcher); > 1 reports wall time per forward / pairs per second of the pipelined stream "
+                    "instead of the latency of a synchronous forward")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("lightglue_amd needs an MI355X (ROCm device type 'cuda'); there is no CPU path to benchmark.")
@@ -92,7 +110,8 @@ def main():
             matcher.compile()
         for kind in results:
             for n in args.num_keypoints:
-                ms = measure(matcher, make_pair(kind, args.batch, n, device), r=args.repeat)["mean"]
+                pair = make_pair(kind, args.batch, n, device)
+                ms = (measure_lanes(matcher, pair, args.lanes, r=args.repeat) if args.lanes > 1 else measure(matcher, pair, r=args.repeat))["mean"]
                 results[kind][name].append(1000.0 * args.batch / ms if args.measure == "throughput" else ms)
         del matcher
     for kind, rows in results.items():

@@ -67,8 +67,9 @@ def _cross_block(d: int) -> nn.Module:  # ref :176-192
 class DeferredMatches:
     """Handle of a forward whose outputs are on their way (LightGlue.forward_deferred)."""
 
-    def __init__(self, done, host_sizes, assemble):
+    def __init__(self, done, host_sizes, assemble, buffers=()):
         self._done, self._host, self._assemble, self._out = done, host_sizes, assemble, None
+        self.buffers = buffers     # the allocations every output tensor is a view of (InflightMatcher hands THEM to the consumer's stream: 3 - 4 record_stream calls, not one per output)
 
     def result(self) -> dict:
         if self._out is None:
@@ -336,6 +337,25 @@ class LightGlue(nn.Module):
         do_compile = bool(self.static_lengths) and max(m, n) <= max(self.static_lengths)
         return self.conf.width_confidence > 0 and not do_compile
 
+    def _carve_plan(self, b, m, n, kmax, pruning):
+        """Sizes and 4-element-aligned offsets of the pieces of the three output allocations (int32 / fp32 / int64), cached per shape."""
+        key = (b, m, n, pruning)
+        cache = self.__dict__.setdefault("_plans", {})
+        plan = cache.get(key)
+        if plan is None:
+            def carve(sizes):
+                off = [0]
+                for x in sizes:
+                    off.append(off[-1] + ((x + 3) & ~3))
+                return off
+            isz = [b * m, b * n, b * kmax * 2, b * m if pruning else 0, b * n if pruning else 0, 3 * b]
+            fsz = [b * m, b * n, b * kmax, 0 if pruning else b * m, 0 if pruning else b * n]
+            lsz = [b * m, b * n, b * kmax * 2, b, b * m if pruning else 0, b * n if pruning else 0]
+            if len(cache) > 256:
+                cache.clear()
+            plan = cache[key] = (isz, carve(isz), fsz, carve(fsz), lsz, carve(lsz))
+        return plan
+
     def forward_raw(self, data: dict, wire: Optional[torch.Tensor] = None) -> dict:
         """The forward without output widening, ragged lists or the host synchronisation: int32 `matches0/1` [B, M|N], fp32
         `matching_scores0/1`, int32 `stop` and `status` [B] — views of the engine's own output buffers, valid on the current stream.
@@ -424,26 +444,22 @@ class LightGlue(nn.Module):
         # last kernel writes the reference's dtypes itself (int64 indices / stop / prune counters, float prune0/1 without pruning, ref :616-629;
         # round-5 extension of lg_forward_io): no framework kernel runs between or behind the engine's launches.
         kmax = min(m, n)
-        r4 = lambda x: (x + 3) & ~3
-        carve = lambda sizes: [sum(r4(x) for x in sizes[:k]) for k in range(len(sizes) + 1)]
-        isz = [b * m, b * n, b * kmax * 2, b * m if do_point_pruning else 0, b * n if do_point_pruning else 0, 3 * b]
-        ioff = carve(isz)
+        plan = self._carve_plan(b, m, n, kmax, do_point_pruning)      # offsets of the pieces (cached per shape: the host path of a B = 1 forward is ~0.3 ms, and this was a tenth of it)
+        isz, ioff, fsz, foff, lsz, loff = plan
         ibuf = torch.empty((ioff[-1],), device=device, dtype=torch.int32)
-        ipiece = lambda buf, off, sz, k, *shape: buf[off[k]: off[k] + sz[k]].view(*shape)
+
+        def ipiece(buf, off, sz, k, *shape):
+            return buf[off[k]: off[k] + sz[k]].view(shape)
         m0, m1, mlist = ipiece(ibuf, ioff, isz, 0, b, m), ipiece(ibuf, ioff, isz, 1, b, n), ipiece(ibuf, ioff, isz, 2, b, kmax, 2)
         prune0_i32 = ipiece(ibuf, ioff, isz, 3, b, m) if do_point_pruning else None
         prune1_i32 = ipiece(ibuf, ioff, isz, 4, b, n) if do_point_pruning else None
         stop_nm = ipiece(ibuf, ioff, isz, 5, 3, b)              # [0] = stop, [1] = n_matches, [2] = status (LG_OK / LG_ERR_RANGE / LG_ERR_DEVICE)
-        fsz = [b * m, b * n, b * kmax, 0 if do_point_pruning else b * m, 0 if do_point_pruning else b * n]
-        foff = carve(fsz)
         fbuf = torch.empty((foff[-1],), device=device, dtype=torch.float32)
         ms0, ms1 = ipiece(fbuf, foff, fsz, 0, b, m), ipiece(fbuf, foff, fsz, 1, b, n)
         mscore_list = ipiece(fbuf, foff, fsz, 2, b, kmax)
         raw_mode = _raw is not False
-        m0_64 = m1_64 = mlist64 = stop64 = prune0 = prune1 = None
+        m0_64 = m1_64 = mlist64 = stop64 = prune0 = prune1 = lbuf = None
         if not raw_mode:
-            lsz = [b * m, b * n, b * kmax * 2, b, b * m if do_point_pruning else 0, b * n if do_point_pruning else 0]
-            loff = carve(lsz)
             lbuf = torch.empty((loff[-1],), device=device, dtype=torch.int64)
             m0_64, m1_64 = ipiece(lbuf, loff, lsz, 0, b, m), ipiece(lbuf, loff, lsz, 1, b, n)
             mlist64, stop64 = ipiece(lbuf, loff, lsz, 2, b, kmax, 2), ipiece(lbuf, loff, lsz, 3, b)
@@ -478,8 +494,8 @@ class LightGlue(nn.Module):
             None if (do_point_pruning or raw_mode) else ptr(prune0), None if (do_point_pruning or raw_mode) else ptr(prune1),
             ptr(wire), 0 if wire is None else wire.stride(0), stop_nm[2].data_ptr())
         with torch.cuda.device(device):
-            stream = torch.cuda.current_stream(device).cuda_stream
-            _cabi.check(_cabi.load().lg_engine_forward(handle, C.byref(io), C.c_void_p(stream)))
+            cur_stream = torch.cuda.current_stream(device)
+            _cabi.check(_cabi.load().lg_engine_forward(handle, C.byref(io), C.c_void_p(cur_stream.cuda_stream)))
 
         if getattr(self, "_debug_step", -1) >= 0:  # test tap: the pipeline stopped early, outputs are not written
             torch.cuda.synchronize(device)
@@ -513,8 +529,8 @@ class LightGlue(nn.Module):
             hbuf = torch.empty((3, b), dtype=torch.int32, pin_memory=True)
             hbuf.copy_(stop_nm, non_blocking=True)
             done = torch.cuda.Event()
-            done.record(torch.cuda.current_stream(device))
-            return DeferredMatches(done, hbuf, assemble)
+            done.record(cur_stream)
+            return DeferredMatches(done, hbuf, assemble, tuple(t for t in (ibuf, fbuf, lbuf, log_assignment) if t is not None))
         return assemble(stop_nm.tolist())  # THE host sync of the forward: the ragged lists need their sizes (and B = 1 its `stop`)
 
     def set_option(self, key: str, value: int, device="cuda"):

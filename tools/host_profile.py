@@ -25,4 +25,5 @@ loop(100); torch.cuda.synchronize()
 t0 = time.perf_counter(); loop(1000); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"N={n} depth={depth}: {1000 / dt:.0f} forwards/s, {dt:.3f} ms per forward")
 pr = cProfile.Profile(); pr.enable(); loop(1000); torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+pstats.Stats(pr).sort_stats("tottime").print_stats(45)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(30)

@@ -257,3 +257,16 @@ def test_similarity_on_planes_equals_the_generic_kernel():
             assert torch.equal(on[key], again[key]), (recipe, key, "second forward")
         assert torch.equal(torch.as_tensor(on["stop"]), torch.as_tensor(off["stop"]))
         assert (on["matches0"] >= 0).any() or n < 8, "the case should produce matches"
+
+
+def test_constructor_space_walk_against_the_oracle():
+    """tools/fuzz_configs.py: seeded random constructor arguments (input_dim 64 ... 256, add_scale_ori, n_layers 1 ... 9, filter_threshold, early stop / pruning alone and
+    together, pruning thresholds around the keypoint counts, image_size absent) x random shapes against the pinned oracle — the axis the fixtures (default constructor)
+    do not walk.  14 cases here (another seed than the 60 + 240 of profiles/r06q_fuzz_configs*.log)."""
+    require_gpu()
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    import fuzz_configs
+    worst = fuzz_configs.run(cases=14, seed=7, verbose=False)
+    assert worst <= SCORE_TOL

@@ -563,6 +563,34 @@ def main():
         except Exception as exc:   # the probe must never cost the bench line
             gather_probe = {"error": repr(exc)[:300]}
 
+    pcie_probe = None
+    if world == 1 and not args.no_gather_probe and lanes is None and not args.no_pipeline:
+        # PCIe-inclusive rate (never `value`: the reference's contract, and this boundary's, is tensors already in HBM): the same K pipelined steps with every batch
+        # starting in PINNED HOST memory, (a) copied on the compute stream in front of its forward (what `batch_to_device` + forward does, ref utils.py:63-69),
+        # (b) through lightglue_amd.prefetch_to_device: two batches ahead on a copy stream, i.e. under the previous forward
+        try:
+            from lightglue_amd import prefetch_to_device
+            host = {k: {kk: vv.cpu().pin_memory() for kk, vv in v.items()} for k, v in data.items()}
+            nbytes = sum(vv.numel() * vv.element_size() for v in host.values() for vv in v.values())
+
+            def run(feed):
+                pend = None
+                for batch in feed:
+                    prev, pend = pend, model.forward_deferred(batch)
+                    if prev is not None: prev.result()
+                res_ = pend.result(); torch.cuda.synchronize(dev)
+                return res_
+            inline = lambda k: ({kk: {k2: v2.to(dev, non_blocking=True) for k2, v2 in vv.items()} for kk, vv in host.items()} for _ in range(k))
+            run(inline(3)); run(prefetch_to_device((host for _ in range(3)), dev, 2))
+            t_i = time.perf_counter(); run(inline(args.steps)); t_i = (time.perf_counter() - t_i) / args.steps * 1e3
+            t_p = time.perf_counter(); p_out = run(prefetch_to_device((host for _ in range(args.steps)), dev, 2)); t_p = (time.perf_counter() - t_p) / args.steps * 1e3
+            pcie_probe = {"host_bytes_per_step": int(nbytes), "ms_per_step_resident": dt / args.steps * 1e3, "ms_per_step_copy_on_compute_stream": t_i, "ms_per_step_prefetched_on_copy_stream": t_p,
+                          "pairs_per_s_copy_on_compute_stream": B / t_i * 1e3, "pairs_per_s_prefetched": B / t_p * 1e3,
+                          "matches_equal_resident_loop": bool(torch.equal(p_out["matches0"], out["matches0"])) if "matches0" in out else None,
+                          "what": "K pipelined steps with the inputs starting in pinned host memory: copied on the compute stream in front of each forward vs lightglue_amd.prefetch_to_device (copy stream, two batches ahead)"}
+        except Exception as exc:   # never costs the bench line
+            pcie_probe = {"error": repr(exc)[:300]}
+
     if rank == 0:
         total_pairs = B * world * args.steps
         value = total_pairs / dt
@@ -664,6 +692,7 @@ def main():
             "value_synchronous_forward": sync_value,   # pairs/s with model(data) per step (host sync inside every forward), N = 1 only
             "rccl": rccl,
             "gather_probe_one_gpu": gather_probe,
+            "pcie_inclusive": pcie_probe,
             # what one step hands back: the same dict at every N — LightGlue.forward's keys / dtypes (ref :619-629), built inside the timed
             # region with ONE deferred host synchronisation per step (N = 1: forward_deferred; N > 1: PairShardedMatcher.issue_local -> Pending.wait)
             "step_output": {k: (str(v.dtype).replace("torch.", "") if torch.is_tensor(v) else f"list[{len(v)}] of {str(v[0].dtype).replace('torch.', '')}" if isinstance(v, list) and v else type(v).__name__)

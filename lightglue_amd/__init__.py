@@ -10,8 +10,8 @@ from .lightglue import LightGlue  # noqa: F401
 from .superpoint import SuperPoint  # noqa: F401
 from .parallel import PairShardedMatcher, shard_range  # noqa: F401
 from .inflight import InflightMatcher  # noqa: F401
-from .glue import batch_to_device, cm_prune, collate_features, extracted_to_image_frame, match_batch, match_pair, rbd  # noqa: F401
+from .glue import batch_to_device, cm_prune, collate_features, extracted_to_image_frame, match_batch, match_pair, prefetch_to_device, rbd  # noqa: F401
 
 __all__ = ["LightGlue", "SuperPoint", "PairShardedMatcher", "InflightMatcher", "shard_range", "match_pair", "match_batch", "collate_features", "extracted_to_image_frame", "rbd", "cm_prune",
-           "batch_to_device"]
+           "batch_to_device", "prefetch_to_device"]
 __version__ = "0.2.0"

@@ -25,6 +25,58 @@ def batch_to_device(batch: Dict[str, Any], device: str = "cpu", non_blocking: bo
     return _apply_to_tensors(batch, lambda t: t.detach().to(device=device, non_blocking=non_blocking))
 
 
+def prefetch_to_device(batches, device="cuda", depth: int = 2):
+    """Host batches -> device batches, up to `depth` of them AHEAD of the consumer, copied on a separate HIP stream (no reference counterpart: the reference's
+    callers do `batch_to_device` on the compute stream, `lightglue/utils.py:63-69`).  For a matcher fed from host memory — features arriving over the network or from
+    an extractor on another device — the host-to-device copy of batch i + 1 then runs under the forward of batch i instead of in front of it (cfg #2: 68 MB per batch,
+    about 1.2 ms over PCIe against a 7.4 ms forward; measured by `bench.py`'s `pcie_inclusive` block).  Tensors that are not in pinned memory are staged through a pinned
+    copy first (a pageable source would make the copy synchronous); pass pinned tensors to avoid that extra host pass.  Every yielded batch is ordered behind its copy on
+    the stream that is current when it is consumed, and its device memory is handed to that stream (`record_stream`), so nothing else is needed before `matcher(batch)`."""
+    import collections
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("prefetch_to_device copies to an MI355X (ROCm device type 'cuda')")
+    if depth < 1:
+        raise ValueError("depth must be >= 1")
+    copy_stream = torch.cuda.Stream(device)
+    queue = collections.deque()
+
+    def stage(batch):
+        def to_dev(t):
+            if t.is_cuda:
+                return t
+            src = t.detach()
+            if not src.is_pinned():
+                src = src.contiguous().pin_memory()
+            return src.to(device, non_blocking=True), src
+        keep = []
+        def conv(t):
+            r = to_dev(t)
+            if isinstance(r, tuple):
+                keep.append(r[1])
+                return r[0]
+            return r
+        with torch.cuda.stream(copy_stream):
+            dev = _apply_to_tensors(batch, conv)
+            done = torch.cuda.Event()
+            done.record(copy_stream)
+        return dev, done, keep           # `keep`: the pinned sources stay alive until the copy has been waited for
+
+    def release(item):
+        dev, done, _keep = item
+        cur = torch.cuda.current_stream(device)
+        cur.wait_event(done)
+        _apply_to_tensors(dev, lambda t: (t.record_stream(cur), t)[1] if t.is_cuda else t)
+        return dev
+
+    for batch in batches:
+        queue.append(stage(batch))
+        if len(queue) > depth:
+            yield release(queue.popleft())
+    while queue:
+        yield release(queue.popleft())
+
+
 def rbd(data: Dict[str, Any]) -> Dict[str, Any]:
     """Strip the leading batch dimension: tensors and per-batch lists/tuples yield their first item, scalars
     (e.g. `stop`) pass through."""

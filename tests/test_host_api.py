@@ -259,3 +259,11 @@ def test_bench_spawns_its_own_ranks_without_a_launcher(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_prefetch_to_device_refuses_a_cpu_target():
+    from lightglue_amd import prefetch_to_device
+    with pytest.raises(RuntimeError, match="MI355X"):
+        next(prefetch_to_device(iter([{}]), "cpu"))
+    with pytest.raises(ValueError):
+        next(prefetch_to_device(iter([{}]), "cuda", depth=0))

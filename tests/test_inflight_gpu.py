@@ -100,3 +100,37 @@ def test_bench_inflight_line():
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["config"]["batches_in_flight"] == 2 and "InflightMatcher" in line["config"]["host_pipelining"]
     assert line["value"] > 0 and line["steps"] == 6
+
+
+@pytest.mark.parametrize("depth", [1, 2, 4])
+def test_prefetch_to_device_feeds_the_same_batches(depth):
+    """lightglue_amd.prefetch_to_device: host batches (pinned and pageable, different shapes in one stream of batches) arrive on the device in order, `depth` ahead on a
+    copy stream; a forward on each yielded batch equals the forward on a plain `.cuda()` copy bit for bit — also when the consumer runs on a stream of its own and
+    through InflightMatcher lanes."""
+    require_gpu()
+    from lightglue_amd import prefetch_to_device
+    sd = synth.make_state_dict(0, recipe="A")
+    model = gpu_util.make_model(sd, "f16x3", depth_confidence=-1, width_confidence=-1)
+    shapes = [(2, 300, 333), (1, 129, 64), (3, 512, 40), (2, 300, 333), (1, 5, 700), (2, 64, 64)]
+    host = []
+    for i, (B, n, m) in enumerate(shapes):
+        b = synth.make_batch(40 + i, B, n, m)
+        t = {k: {kk: torch.from_numpy(np.ascontiguousarray(vv)) for kk, vv in v.items()} for k, v in b.items()}
+        if i % 2 == 0:
+            t = {k: {kk: vv.pin_memory() for kk, vv in v.items()} for k, v in t.items()}
+        host.append(t)
+    plain = [model({k: {kk: vv.cuda() for kk, vv in v.items()} for k, v in h.items()}) for h in host]
+    got = [model(d) for d in prefetch_to_device(iter(host), "cuda", depth)]
+    assert len(got) == len(plain)
+    for g, p in zip(got, plain):
+        _same(g, p)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        got = [model(d) for d in prefetch_to_device(iter(host), "cuda", depth)]
+    side.synchronize()
+    for g, p in zip(got, plain):
+        _same(g, p)
+    lanes = InflightMatcher(model, 2)
+    for g, p in zip(lanes.map(prefetch_to_device(iter(host), "cuda", depth)), plain):
+        _same(g, p)
+    assert list(prefetch_to_device(iter([]), "cuda", depth)) == []

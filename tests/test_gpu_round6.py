@@ -270,3 +270,27 @@ def test_constructor_space_walk_against_the_oracle():
     import fuzz_configs
     worst = fuzz_configs.run(cases=14, seed=7, verbose=False)
     assert worst <= SCORE_TOL
+
+
+def test_synthetically_trained_checkpoint_when_present():
+    """tools/train_synthetic_checkpoint.py trains the unmodified reference module on a synthetic matching task in the build container (47 MB: git-ignored under
+    tests/golden/_local/, so this test skips on a tree without it).  Its attention is 2 - 4 x sharper than the calibrated stand-ins (per-row logit spread up to 116 against
+    recipe D / E's 25).  tools/verify_pretrained.py must hold the bar on it in the default precision — synthetic keypoints and a pair of the task's own distribution, fixed
+    depth and adaptive — with the oracle as the CPU side (pinned against the reference on this very checkpoint in the build container, profiles/r06tr_trained_cpu_pin.log)."""
+    require_gpu()
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    ck = root / "tests" / "golden" / "_local" / "synthetic_trained_L9.pth"
+    pair = ck.with_name("synthetic_task_pair_1024.npz")
+    if not ck.exists():
+        pytest.skip("no trained checkpoint in this tree (tools/train_synthetic_checkpoint.py, build container only)")
+    p = subprocess.run([sys.executable, str(root / "tools" / "verify_pretrained.py"), str(ck)] + ([str(pair)] if pair.exists() else []) + ["--sizes", "512", "1024", "--pairs", "1"],
+                       capture_output=True, text=True, timeout=1500, cwd=str(root))
+    assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-2000:])
+    assert "RESULT: inside the bar" in p.stdout
+    default = p.stdout.split("## precision f16x3, attention_precision")[0]
+    rows = [ln for ln in default.splitlines() if ln.startswith("| ") and ("fixed depth" in ln or "adaptive" in ln)]
+    assert len(rows) >= 4 and all("| 0 / 0 |" in ln and ln.rstrip().endswith("| ok |") for ln in rows), rows
+    assert all(float(ln.split("|")[3]) <= 1e-4 for ln in rows), rows      # measured 7.9e-6: two orders inside the bar

@@ -96,3 +96,20 @@ def test_operand_rounding_emulation_orders():
     assert e[A, "default"] < 1e-3 and e[A, "fast"] < 1e-3 < e[A, "bf16"], e
     assert e[D, "default"] < 1e-3 < e[D, "fast"] < e[D, "bf16"], e
     assert e[D, "fast"] > 10 * e[D, "default"], e      # an order of magnitude: sharp logits need the split on the whole q.k / P.V path
+
+
+def test_oracle_matches_the_reference_on_the_trained_checkpoint_when_present():
+    """The synthetically trained checkpoint (tools/train_synthetic_checkpoint.py; git-ignored, build container only): the oracle restatement against the unmodified
+    reference on it — what lets the oracle stand in for the reference on the GPU box for these weights (tools/verify_pretrained.py --cpu-only)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    ck = root / "tests" / "golden" / "_local" / "synthetic_trained_L9.pth"
+    if not ck.exists() or not Path("/root/reference/lightglue/lightglue.py").exists():
+        pytest.skip("needs the trained checkpoint and the reference checkout (build container)")
+    p = subprocess.run([sys.executable, str(root / "tools" / "verify_pretrained.py"), str(ck), "--cpu-only", "--sizes", "256", "--pairs", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    rows = [ln for ln in p.stdout.splitlines() if ln.startswith("| synthetic")]
+    assert len(rows) == 2 and all("| 0 / 0 |" in ln and "equal | equal" in ln for ln in rows), rows

@@ -196,6 +196,29 @@ def main():
                 refs = [{k: (gold[k][b] if k != "stop" else int(gold[k][b])) for k in ("matches0", "matches1", "matching_scores0", "matching_scores1", "stop", "prune0", "prune1")}
                         for b in range(case["B"])]
                 ok &= compare(f"fixture {a.fixture} (reference outputs stored in tests/golden)", model(td), refs, case["B"])
+    if not gpu and ref_mod is not None:
+        # build container: pin the ORACLE on this checkpoint — the restatement (what stands in for the reference on the GPU box) against the unmodified reference, CPU fp32 both
+        print("\n## oracle (oracle/lightglue_oracle.py, torch-kernel backend) against the unmodified reference on this checkpoint, CPU fp32\n")
+        print("| case | index mismatches side 0 / 1 | max \\|d score\\| | stop layers | prune counters |")
+        print("|---|---|---|---|---|")
+        for label, data, conf_kw in cases:
+            B = data["image0"]["keypoints"].shape[0]
+            run_ref = cpu_side(ref_mod, sd, arch, conf_kw, a.prune_threshold)
+            run_orc = cpu_side(None, sd, arch, conf_kw, a.prune_threshold)
+            flips = [0, 0]; maxd = 0.0; stops = True; prunes = True
+            for b in range(B):
+                one = {k: {kk: vv[b:b + 1] for kk, vv in v.items()} for k, v in data.items()}
+                r, o = run_ref(one), run_orc(one)
+                for side in (0, 1):
+                    same = r[f"matches{side}"] == o[f"matches{side}"]
+                    flips[side] += int((~same).sum())
+                    d = np.abs(r[f"matching_scores{side}"] - o[f"matching_scores{side}"])[same]
+                    maxd = max(maxd, float(d.max()) if d.size else 0.0)
+                    prunes &= bool(np.array_equal(np.asarray(r[f"prune{side}"], np.float64), np.asarray(o[f"prune{side}"], np.float64)))
+                stops &= r["stop"] == o["stop"]
+            good = flips == [0, 0] and maxd <= 1e-5 and stops and prunes
+            ok &= good
+            print(f"| {label} | {flips[0]} / {flips[1]} | {maxd:.2e} | {'equal' if stops else 'DIFFER'} | {'equal' if prunes else 'DIFFER'} |", flush=True)
     layer_statistics(sd, arch, {k: {kk: vv[:1] for kk, vv in v.items()} for k, v in stats_data.items()})
     print("\nRESULT:", "inside the bar (0 index mismatches, |d score| <= 1e-3, stop layers and prune counters equal) on every default-precision case" if ok else "OUTSIDE THE BAR on at least one default-precision case")
     sys.exit(0 if ok else 1)

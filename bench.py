@@ -136,7 +136,7 @@ def _port_over_reference(n, threads):
     return row["N=512" if n <= 768 else "N=1024"]
 
 
-def cpu_baseline(sd, n, m, gpu_out=None, budget_s=20.0, max_pairs=32, recipe="A", conf_kw=None, dim=256, wseed=0):
+def cpu_baseline(sd, n, m, gpu_out=None, budget_s=20.0, max_pairs=32, recipe="A", conf_kw=None, dim=256, wseed=0, checkpoint=None):
     """CPU leg (rank 0, N = 1 only; ~30 s in total) — run by oracle/cpu_leg.py IN ITS OWN PROCESS: affinity set before torch is imported (whole L3 domains of one
     socket, one hardware thread per physical core, not CPU 0's domain), a FIXED thread count, the same k pairs timed five times (median + spread), cfg #1 (N = 512,
     B = 1) at 1 and N threads beside it.  The port of the reference's CPU fp32 path (oracle/, torch-kernel backend) is timed on pairs of the SAME seeded batch the
@@ -149,6 +149,8 @@ def cpu_baseline(sd, n, m, gpu_out=None, budget_s=20.0, max_pairs=32, recipe="A"
         out_npz = os.path.join(tmp, "cpu_leg.npz")
         cmd = [sys.executable, str(ROOT / "oracle" / "cpu_leg.py"), "--n", str(n), "--m", str(m), "--dim", str(dim), "--recipe", recipe, "--wseed", str(wseed),
                "--conf", json.dumps(conf), "--threads", str(CPU_LEG_THREADS), "--budget", str(budget_s), "--max-pairs", str(max_pairs), "--out", out_npz]
+        if checkpoint:
+            cmd += ["--checkpoint", str(checkpoint)]
         env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "MKL_NUM_THREADS")}
         # glibc malloc: keep the forward's large temporaries (16 MB attention matrices, ...) in the heap instead of mmap / munmap per tensor — page-fault churn was
         # the main source of the round-to-round wobble, and costs the CPU side ~25 % (build container: 3.21 -> 4.08 pairs/s, round spread 13 % -> 3.5 %)
@@ -255,6 +257,8 @@ def main():
     ap.add_argument("--kpts", type=int, default=None, help="keypoints per image, N = M (default: the config's)")
     ap.add_argument("--recipe", default=None, choices=["A", "C", "D"], help="seeded weights / inputs (default: the config's): A (SURVEY 8c, the headline), C (adaptive: mixed stop depths) or D (trained-model "
                     "statistics: attention logit spread 25, LayerNorm gains in [0.5, 4], residual rms ~27, descriptor norms in [0.5, 3])")
+    ap.add_argument("--checkpoint", default=None, help="weights from a state-dict file (module-tree names, e.g. tools/train_synthetic_checkpoint.py's) instead of the seeded recipe; the oracle leg loads the same file; "
+                    "a labelled extra run, never the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-probe", action="store_true", help="one GPU: skip the K extra steps that measure what the (world-of-one) side-stream result gather costs a step")
     ap.add_argument("--no-pipeline", action="store_true", help="one GPU: synchronous forward per step (no deferred output assembly)")
@@ -317,6 +321,8 @@ def main():
     if dim != 256:
         conf_kw["input_dim"] = dim
     sd = synthetic.make_state_dict(cfg["wseed"], recipe=args.recipe, input_dim=dim)
+    if args.checkpoint:
+        sd = {k: v.float().numpy() for k, v in torch.load(args.checkpoint, map_location="cpu").items() if torch.is_tensor(v)}
     model = LightGlue(features=None, precision=args.precision, attention_precision=args.attention, **conf_kw).eval()
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     if os.environ.get("LG_BENCH_ABLATION") == "1":   # timing ablations (variant libraries that compute garbage on purpose): no range guard, no parity block
@@ -640,7 +646,7 @@ def main():
             "config": {"baseline_config": cfg["label"] if (B, n, m) == (cfg["pairs"], cfg["n"], cfg["m"]) else f"{cfg['label']} — with --pairs / --kpts overrides: batch={B}, N={n}, M={m}",
                        "workload": (f"SuperPoint-dim 256-d descriptors, N=M={n}, 9 layers, pruning/early-stop OFF, batch={B} pairs per GPU, " if args.config == 2 else
                                     f"{dim}-d descriptors, N={n} M={m}, 9 layers, {'depth_confidence=0.95 width_confidence=0.99 (early stop + point pruning ON, every pair on its own)' if adaptive else 'pruning/early-stop OFF'}, batch={B} pairs per GPU, ")
-                                   + f"seeded random weights (recipe {args.recipe}{', trained-model statistics' if args.recipe == 'D' else ''}), precision={args.precision}"
+                                   + (f"weights from {Path(args.checkpoint).name}" if args.checkpoint else f"seeded random weights (recipe {args.recipe}{', trained-model statistics' if args.recipe == 'D' else ''})") + f", precision={args.precision}"
                                    + (" (split-f16 operands, 3 MFMAs per product, for every contraction incl. q k^T and P V; fp32 accumulate / residual / softmax)" if args.precision == "f16x3" and not args.attention else "")
                                    + (", attention_precision=fp16 (single-plane f16 attention: the fast opt-in, outside the 1e-3 bar for sharp attention)" if args.attention else ""),
                        "pairs_per_gpu": B, "keypoints": n, "keypoints1": m, "descriptor_dim": dim, "parallelism": f"pair-sharded dp{world}", "batches_in_flight": (args.inflight if lanes is not None else 1),
@@ -700,10 +706,10 @@ def main():
         }
         # match-index parity of the batch that was just timed (rank 0's pairs): against the reference's own fixture for the
         # first 4 pairs and against the oracle on the pairs the CPU leg runs anyway
-        default_weights = args.precision in ("f16x3", "fp32")
+        default_weights = args.precision in ("f16x3", "fp32") and not args.checkpoint
         res["parity"] = golden_parity(out, n, B, args.recipe, args.config, m) if (default_weights and os.environ.get("LG_BENCH_ABLATION") != "1") else None
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"], res["parity_oracle"] = cpu_baseline(sd, n, m, gpu_out=out, recipe=args.recipe, conf_kw={k: v for k, v in conf_kw.items() if k != "input_dim"}, dim=dim, wseed=cfg["wseed"])
+            res["cpu_baseline"], res["parity_oracle"] = cpu_baseline(sd, n, m, gpu_out=out, recipe=args.recipe, conf_kw={k: v for k, v in conf_kw.items() if k != "input_dim"}, dim=dim, wseed=cfg["wseed"], checkpoint=args.checkpoint)
         json_out.write(json.dumps(res) + "\n")
         json_out.flush()
     if world > 1:

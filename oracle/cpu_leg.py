@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--conf", default='{"depth_confidence": -1, "width_confidence": -1}')
     ap.add_argument("--threads", type=int, default=16); ap.add_argument("--budget", type=float, default=20.0); ap.add_argument("--max-pairs", type=int, default=32)
     ap.add_argument("--rounds", type=int, default=5); ap.add_argument("--out", default=None); ap.add_argument("--no-reference", action="store_true")
+    ap.add_argument("--checkpoint", default=None, help="a state dict file (module-tree names, torch.save) instead of the seeded recipe weights (bench.py --checkpoint)")
     args = ap.parse_args()
 
     cores, where = choose_cores(args.threads)
@@ -115,6 +116,8 @@ def main():
     conf = O.make_conf(**conf_kw)
     kw = dict(synthetic.RECIPE_D_DATA) if args.recipe == "D" else {}
     sd = synthetic.make_state_dict(args.wseed, recipe=args.recipe, input_dim=args.dim)
+    if args.checkpoint:
+        sd = {k: v.float().numpy() for k, v in torch.load(args.checkpoint, map_location="cpu").items() if torch.is_tensor(v)}
     n, m = args.n, args.m
     fwd = lambda d: O.forward(sd, conf, d, backend="torch")
 

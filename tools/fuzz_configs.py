@@ -5,7 +5,7 @@ thresholds below / above the keypoint counts, image_size present or absent (boun
 The fixtures and the seed sweeps hold the data axis at the default constructor; this holds the constructor axis.  Bar = the product's: scores within 1e-3, indices equal
 up to flips the oracle's own decision boundaries explain (tests/conftest.py), stop layers and prune counters equal.
 
-usage: fuzz_configs.py [--cases 40] [--seed 0]      (exit code 1 on the first failing case, which is printed with its full recipe)"""
+usage: fuzz_configs.py [--cases 40] [--seed 0] [--checkpoint trained.pth]      (exit code 1 on the first failing case, which is printed with its full recipe)"""
 import argparse
 import sys
 from pathlib import Path
@@ -31,8 +31,13 @@ def draw(rng):
     return case
 
 
+CHECKPOINT = None      # --checkpoint: a trained state dict (256-d, 9 layers) instead of the seeded recipes — the walk then covers shapes, thresholds and adaptivity modes on ITS heads
+
+
 def run_case(case):
     recipe = "C" if case["adaptive"] else "A"
+    if CHECKPOINT is not None:
+        case.update(dim=256, sift=False, n_layers=9)
     kw = dict(n_layers=case["n_layers"], filter_threshold=case["filter_threshold"],
               depth_confidence=case["depth_confidence"] if case["adaptive"] in (1, 3) else -1,
               width_confidence=case["width_confidence"] if case["adaptive"] in (2, 3) else -1)
@@ -40,7 +45,7 @@ def run_case(case):
         kw["input_dim"] = case["dim"]
     if case["sift"]:
         kw["add_scale_ori"] = True
-    sd = synth.make_state_dict(case["wseed"], input_dim=case["dim"], add_scale_ori=case["sift"], n_layers=case["n_layers"], recipe=recipe)
+    sd = CHECKPOINT if CHECKPOINT is not None else synth.make_state_dict(case["wseed"], input_dim=case["dim"], add_scale_ori=case["sift"], n_layers=case["n_layers"], recipe=recipe)
     data = synth.make_batch(case["dseed"], case["B"], case["n"], case["m"], case["dim"], add_scale_ori=case["sift"])
     if case["drop_size"]:
         for img in ("image0", "image1"):
@@ -84,5 +89,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--checkpoint", default=None, help="state-dict file (module-tree names; tools/train_synthetic_checkpoint.py): its weights in every case")
     a = ap.parse_args()
+    if a.checkpoint:
+        CHECKPOINT = {k: v.float().numpy() for k, v in torch.load(a.checkpoint, map_location="cpu").items() if torch.is_tensor(v)}
     run(a.cases, a.seed)

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = (
     "lg_engine_debug_stop_after", "lg_engine_debug_read", "lg_engine_debug_caps",
     "lg_profile_num_classes", "lg_profile_class_name", "lg_engine_profile_enable", "lg_engine_profile_read",
     "lg_sp_sample_descriptors", "lg_sp_detect_workspace_bytes", "lg_sp_detect",
-    "lg_sp_pack_conv_weight", "lg_sp_encode_workspace_bytes", "lg_sp_encode", "lg_debug_mfma_sustained",
+    "lg_sp_pack_conv_weight", "lg_sp_encode_workspace_bytes", "lg_sp_encode", "lg_sp_pack_conv_weight_split", "lg_sp_encode_split", "lg_debug_mfma_sustained",
 )
 
 
@@ -124,6 +124,8 @@ def load() -> C.CDLL:
     lib.lg_sp_encode_workspace_bytes.argtypes = [C.c_int32] * 3
     lib.lg_sp_encode_workspace_bytes.restype = C.c_int64
     lib.lg_sp_encode.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.lg_sp_pack_conv_weight_split.argtypes = lib.lg_sp_pack_conv_weight.argtypes
+    lib.lg_sp_encode_split.argtypes = lib.lg_sp_encode.argtypes
     lib.lg_debug_mfma_sustained.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]
     _lib = lib
     return lib

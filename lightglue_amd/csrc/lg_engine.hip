@@ -735,7 +735,23 @@ int lg_sp_encode(const float* image, int32_t batch, int32_t h, int32_t w, const 
     if (!image || !params || !workspace || !scores || !desc_map) return fail(LG_ERR_INVALID, "null pointer");
     if (workspace_bytes < lg_sp_encode_workspace_bytes(batch, h, w)) return fail(LG_ERR_INVALID, "workspace too small (lg_sp_encode_workspace_bytes)");
     for (int i = 0; i < 24; ++i) if (!params[i]) return fail(LG_ERR_INVALID, "null layer parameter");
-    HIPCHK(launch_sp_encode(image, batch, h, w, params, static_cast<float*>(workspace), scores, desc_map, static_cast<hipStream_t>(hip_stream)));
+    HIPCHK(launch_sp_encode(image, batch, h, w, params, static_cast<float*>(workspace), scores, desc_map, 0, static_cast<hipStream_t>(hip_stream)));
+    return LG_OK;
+}
+
+int lg_sp_pack_conv_weight_split(const float* src, int32_t cout, int32_t cin, int32_t k, void* dst, void* hip_stream) {
+    if (!src || !dst || cout < 1 || cin < 32 || cin % 32 || (k != 1 && k != 3) || (k == 3 && cout % 64)) return fail(LG_ERR_INVALID, "bad conv weight (split form: cin a multiple of 32; 3 x 3 layers: cout a multiple of 64)");
+    HIPCHK(launch_sp_pack_weight_split(src, dst, cout, cin, k, static_cast<hipStream_t>(hip_stream)));
+    return LG_OK;
+}
+
+int lg_sp_encode_split(const float* image, int32_t batch, int32_t h, int32_t w, const float* const* params, void* workspace,
+                       int64_t workspace_bytes, float* scores, float* desc_map, void* hip_stream) {
+    if (batch < 1 || h < 8 || w < 8) return fail(LG_ERR_INVALID, "image height / width must be at least 8");
+    if (!image || !params || !workspace || !scores || !desc_map) return fail(LG_ERR_INVALID, "null pointer");
+    if (workspace_bytes < lg_sp_encode_workspace_bytes(batch, h, w)) return fail(LG_ERR_INVALID, "workspace too small (lg_sp_encode_workspace_bytes)");
+    for (int i = 0; i < 24; ++i) if (!params[i]) return fail(LG_ERR_INVALID, "null layer parameter");
+    HIPCHK(launch_sp_encode(image, batch, h, w, params, static_cast<float*>(workspace), scores, desc_map, 1, static_cast<hipStream_t>(hip_stream)));
     return LG_OK;
 }
 

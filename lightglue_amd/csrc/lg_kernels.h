@@ -247,7 +247,8 @@ struct SpDetectArgs {
 constexpr int SP_TOPK_MAX = 4096;
 // SuperPoint conv stack (lg_sp_encoder.hip): image [B][1][H][W] (any H, W >= 8; floor pooling) -> scores [B][H/8*8][W/8*8], raw descriptor map
 // [B][256][H/8][W/8]; P = 24 device pointers (packed weight, bias) x 12 layers; ws = 2 * B*H*W*64 floats
-hipError_t launch_sp_encode(const float* image, int B, int H, int W, const float* const* P, float* ws, float* scores, float* desc_map, hipStream_t s);
+hipError_t launch_sp_encode(const float* image, int B, int H, int W, const float* const* P, float* ws, float* scores, float* desc_map, int split, hipStream_t s);
+hipError_t launch_sp_pack_weight_split(const float* src, void* dst, int Cout, int Cin, int k, hipStream_t s);
 hipError_t launch_sp_pack_weight(const float* src, float* dst, int Cout, int Cin, int k, hipStream_t s);
 hipError_t launch_sp_detect(const SpDetectArgs& a, hipStream_t s);
 

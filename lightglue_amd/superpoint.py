@@ -23,7 +23,10 @@ _LAYERS = ("conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a",
 
 class SuperPoint(nn.Module):
     default_conf = {"descriptor_dim": 256, "nms_radius": 4, "max_num_keypoints": None, "detection_threshold": 0.0005,
-                    "remove_borders": 4}   # ref :108-114
+                    "remove_borders": 4,   # ref :108-114
+                    # extension: "fp32" = exact f32 MFMA convolutions (default); "f16x3" = split-f16 operands, three f16 MFMAs per product, fp32 accumulation (22 operand bits:
+                    # below an fp32 convolution's summation-order noise, cf. the reference's own GPU default of TF32 convolutions) at several times the f32 MFMA rate
+                    "conv_precision": "fp32"}
     required_data_keys = ["image"]
 
     def __init__(self, weights: Optional[dict] = None, **conf):
@@ -40,6 +43,8 @@ class SuperPoint(nn.Module):
         self.convDa = nn.Conv2d(c4, c5, 3, 1, 1); self.convDb = nn.Conv2d(c5, self.conf.descriptor_dim, 1, 1, 0)
         if self.conf.descriptor_dim != 256:
             raise ValueError("lightglue_amd builds descriptor_dim = 256 only")
+        if self.conf.conv_precision not in ("fp32", "f16x3"):
+            raise ValueError("conv_precision must be 'fp32' or 'f16x3'")
         if self.conf.max_num_keypoints is not None and self.conf.max_num_keypoints <= 0:
             raise ValueError("max_num_keypoints must be positive or None")   # ref :146-147
         if weights is not None:
@@ -48,7 +53,8 @@ class SuperPoint(nn.Module):
 
     # ------------------------------------------------------------------ weights -> kernel layout
     def _params(self, device):
-        sig = (str(device),) + tuple((p._version, p.data_ptr()) for p in self.parameters())
+        split = self.conf.conv_precision == "f16x3"
+        sig = (str(device), split) + tuple((p._version, p.data_ptr()) for p in self.parameters())
         if self._packed is not None and self._packed[0] == sig:
             return self._packed[1]
         lib = _cabi.load()
@@ -60,7 +66,8 @@ class SuperPoint(nn.Module):
                 w = conv.weight.detach().to(device=device, dtype=torch.float32).contiguous()
                 cout, cin, k, _ = w.shape
                 dst = torch.empty(w.numel(), device=device, dtype=torch.float32)
-                _cabi.check(lib.lg_sp_pack_conv_weight(w.data_ptr(), cout, cin, k, dst.data_ptr(), C.c_void_p(stream)))
+                pack = lib.lg_sp_pack_conv_weight_split if (split and name != "conv1a") else lib.lg_sp_pack_conv_weight   # (the split form fills the same bytes: two f16 planes)
+                _cabi.check(pack(w.data_ptr(), cout, cin, k, dst.data_ptr(), C.c_void_p(stream)))
                 out += [dst, conv.bias.detach().to(device=device, dtype=torch.float32).contiguous()]
             torch.cuda.current_stream(device).synchronize()   # `w` temporaries may be freed after this
         self._packed = (sig, out)
@@ -92,8 +99,8 @@ class SuperPoint(nn.Module):
         dense = torch.empty((bsz, 256, h // 8, w // 8), device=device, dtype=torch.float32)
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
-            _cabi.check(lib.lg_sp_encode(image.data_ptr(), bsz, h, w, arr, work.data_ptr(), nbytes, scores.data_ptr(), dense.data_ptr(),
-                                         C.c_void_p(stream)))
+            encode = lib.lg_sp_encode_split if self.conf.conv_precision == "f16x3" else lib.lg_sp_encode
+            _cabi.check(encode(image.data_ptr(), bsz, h, w, arr, work.data_ptr(), nbytes, scores.data_ptr(), dense.data_ptr(), C.c_void_p(stream)))
         return scores, dense
 
     # ------------------------------------------------------------------ the reference's forward

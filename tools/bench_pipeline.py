@@ -4,7 +4,7 @@ pair through ONE extractor forward (2B images, top-k keypoints, ragged counts ca
 (seeded; the released checkpoints are network-only) and random images: the numbers are the pipeline's cost, not its matching quality.  Reports ms per step and image
 pairs/s for the extractor alone, the matcher alone on the extractor's output, and both.
 
-usage: bench_pipeline.py [--pairs 8] [--kpts 1024] [--sizes 480x640,768x1024] [--steps 20]"""
+usage: bench_pipeline.py [--pairs 8] [--kpts 1024] [--sizes 480x640,768x1024] [--steps 20] [--conv-precision fp32|f16x3]"""
 import argparse
 import sys
 import time
@@ -36,8 +36,9 @@ def main():
     ap.add_argument("--kpts", type=int, default=1024)
     ap.add_argument("--sizes", default="480x640,768x1024")
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--conv-precision", default="fp32", choices=["fp32", "f16x3"], help="the extractor's convolution arithmetic (lightglue_amd.SuperPoint conv_precision)")
     a = ap.parse_args()
-    ext = SuperPoint(weights=G.encoder_state_dict(0), max_num_keypoints=a.kpts).cuda().eval()
+    ext = SuperPoint(weights=G.encoder_state_dict(0), max_num_keypoints=a.kpts, conv_precision=a.conv_precision).cuda().eval()
     matcher = gpu_util.make_model(synth.make_state_dict(0, recipe="A"), "f16x3", depth_confidence=-1, width_confidence=-1)
     B = a.pairs
     for size in a.sizes.split(","):
@@ -56,7 +57,7 @@ def main():
         t_m, out = timed(lambda: matcher(data), a.steps)
         t_b, out = timed(lambda: matcher(extract()), a.steps)
         n = data["image0"]["num_keypoints"].float().mean().item()
-        print(f"{h}x{w}, {B} pairs per step, {n:.0f} keypoints per image on average (cap {a.kpts}): extractor {t_e * 1e3:6.2f} ms ({2 * B / t_e:6.0f} images/s), "
+        print(f"[{a.conv_precision}] {h}x{w}, {B} pairs per step, {n:.0f} keypoints per image on average (cap {a.kpts}): extractor {t_e * 1e3:6.2f} ms ({2 * B / t_e:6.0f} images/s), "
               f"matcher {t_m * 1e3:6.2f} ms ({B / t_m:6.0f} pairs/s), images -> matches {t_b * 1e3:6.2f} ms = {B / t_b:6.0f} image pairs/s; matches per pair {sum(len(x) for x in out['matches']) / B:.0f}", flush=True)
 
 

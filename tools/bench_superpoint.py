@@ -16,12 +16,15 @@ def flops(h, w):
     return sum(2.0 * k * ci * co * h * w / d for ci, co, k, d in L)
 
 
-model = SuperPoint(weights=G.encoder_state_dict(0), max_num_keypoints=2048).cuda().eval()
-for (b, h, w) in ((8, 480, 640), (8, 768, 1024)):
-    img = torch.rand(b, 1, h, w, device="cuda")
-    for name, fn in (("conv stack", lambda: model.encode(img)), ("full extract", lambda: model({"image": img}))):
-        for _ in range(3): fn()
-        torch.cuda.synchronize(); t0 = time.perf_counter(); reps = 10
-        for _ in range(reps): fn()
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
-        print(f"{name:13s} B={b} {h}x{w}: {dt * 1e3:7.2f} ms/batch  {b / dt:8.1f} images/s  {flops(h, w) * b / dt / 1e12:6.1f} TFLOP/s fp32 ({flops(h, w) * b / dt / 157.3e12 * 100:4.1f} % of the 157 TF f32 MFMA peak)")
+for prec in ("fp32", "f16x3"):
+    model = SuperPoint(weights=G.encoder_state_dict(0), max_num_keypoints=2048, conv_precision=prec).cuda().eval()
+    for (b, h, w) in ((8, 480, 640), (8, 768, 1024)):
+        img = torch.rand(b, 1, h, w, device="cuda")
+        for name, fn in (("conv stack", lambda: model.encode(img)), ("full extract", lambda: model({"image": img}))):
+            for _ in range(3): fn()
+            torch.cuda.synchronize(); t0 = time.perf_counter(); reps = 10
+            for _ in range(reps): fn()
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+            peak = 157.3e12 if prec == "fp32" else 2500e12
+            print(f"{prec:5s} {name:13s} B={b} {h}x{w}: {dt * 1e3:7.2f} ms/batch  {b / dt:8.1f} images/s  {flops(h, w) * b / dt / 1e12:6.1f} TFLOP/s algorithmic "
+                  f"({flops(h, w) * b / dt / peak * 100:4.1f} % of the {'157 TF f32' if prec == 'fp32' else '2 500 TF f16 (x3 MFMAs per product issued)'} MFMA peak)")

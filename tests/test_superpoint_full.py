@@ -109,3 +109,26 @@ def test_extractor_feeds_the_matcher():
     matcher = gpu_util.make_model(synth.make_state_dict(0, recipe="A"), "f16x3", depth_confidence=-1, width_confidence=-1)
     out = rbd(matcher({"image0": f0, "image1": f1}))
     assert out["matches0"].shape == (128,) and out["matches"].shape[1] == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 333, 517), (1, 8, 8), (3, 40, 1000), (1, 1025, 31)])
+def test_split_conv_stack_agrees_with_the_exact_form_at_odd_sizes(shape):
+    """The LDS-staged split-f16 convolution (conv_precision "f16x3") against the exact-fp32 kernels on sizes the fixtures do not hold: widths / heights that are no
+    multiples of the 32 x 8 pixel tile at every pyramid level, one-tile images, very wide and very tall ones, batch > 1 — halo staging, zero padding and the pooled /
+    unpooled epilogues at every edge.  Tolerance = the split form's own round-off against fp32 (22 vs 24 operand bits through twelve layers)."""
+    require_gpu()
+    from lightglue_amd import SuperPoint
+    B, H, W = shape
+    sd = G.encoder_state_dict(5)
+    img = torch.from_numpy(G.encoder_image(77, B, H, W)).cuda()
+    exact = SuperPoint(weights=sd, conv_precision="fp32").cuda().eval()
+    split = SuperPoint(weights=sd, conv_precision="f16x3").cuda().eval()
+    s0, d0 = exact.encode(img)
+    s1, d1 = split.encode(img)
+    assert s0.shape == s1.shape and d0.shape == d1.shape
+    np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy(), atol=1e-5, rtol=2e-4)
+    scale = float(d0.abs().max())
+    assert float((d1 - d0).abs().max()) <= 2e-5 * max(scale, 1.0), (float((d1 - d0).abs().max()), scale)
+    again = split.encode(img)
+    assert torch.equal(again[0], s1) and torch.equal(again[1], d1)          # deterministic

@@ -247,7 +247,7 @@ int lg_sp_encode(const float* image, int32_t batch, int32_t h, int32_t w, const 
  * multiple of the f32 MFMA rate.  Values must lie inside the f16 range (|x| < 65504); conv1a (K = 9) stays fp32.
  * lg_sp_pack_conv_weight_split: [cout][cin][k][k] fp32 -> hi / lo f16 planes in the order the kernels read (k = 1: [2 planes][cout][cin]; k = 3: MFMA-fragment order
  *   [cout / 64][cin / 32][tap][4 n-tiles][2 planes][64 lanes][8], cout % 64 == 0); dst holds cout*cin*k*k*4 BYTES (as the fp32 form).  cin % 32 == 0.
- * lg_sp_encode_split: as lg_sp_encode; params[0..1] (conv1a) packed by lg_sp_pack_conv_weight, the weights of the other eleven layers by lg_sp_pack_conv_weight_split. */
+ * lg_sp_encode_split: as lg_sp_encode, for images of h * w < 2^25 pixels (32-bit element offsets inside one image; larger ones are refused); params[0..1] (conv1a) packed by lg_sp_pack_conv_weight, the weights of the other eleven layers by lg_sp_pack_conv_weight_split. */
 int lg_sp_pack_conv_weight_split(const float* src, int32_t cout, int32_t cin, int32_t k, void* dst, void* hip_stream);
 int lg_sp_encode_split(const float* image, int32_t batch, int32_t h, int32_t w, const float* const* params, void* workspace,
                        int64_t workspace_bytes, float* scores, float* desc_map, void* hip_stream);

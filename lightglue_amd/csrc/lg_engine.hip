@@ -748,6 +748,8 @@ int lg_sp_pack_conv_weight_split(const float* src, int32_t cout, int32_t cin, in
 int lg_sp_encode_split(const float* image, int32_t batch, int32_t h, int32_t w, const float* const* params, void* workspace,
                        int64_t workspace_bytes, float* scores, float* desc_map, void* hip_stream) {
     if (batch < 1 || h < 8 || w < 8) return fail(LG_ERR_INVALID, "image height / width must be at least 8");
+    // sp_conv3x3_split_kernel addresses the pixels of ONE image with 32-bit element offsets (h w 64 channels at full resolution)
+    if ((int64_t)h * w * 64 >= (int64_t)1 << 31) return fail(LG_ERR_INVALID, "split-f16 conv stack: h * w must stay below 2^25 pixels (use conv_precision = fp32 for larger images)");
     if (!image || !params || !workspace || !scores || !desc_map) return fail(LG_ERR_INVALID, "null pointer");
     if (workspace_bytes < lg_sp_encode_workspace_bytes(batch, h, w)) return fail(LG_ERR_INVALID, "workspace too small (lg_sp_encode_workspace_bytes)");
     for (int i = 0; i < 24; ++i) if (!params[i]) return fail(LG_ERR_INVALID, "null layer parameter");

@@ -91,6 +91,12 @@ def test_argument_validation_without_gpu():
     assert lib.lg_engine_set_option(h, b"no_such_option", 1) == _cabi.LG_ERR_INVALID and b"no_such_option" in lib.lg_last_error()
     assert lib.lg_engine_set_option(h, b"tail_variant", 1) == _cabi.LG_ERR_INVALID
     lib.lg_engine_destroy(h)
+    # the split-f16 conv stack addresses one image with 32-bit element offsets: larger images are refused before anything is touched
+    fake = ctypes.c_void_p(16)
+    arr = (ctypes.c_void_p * 24)(*[16] * 24)
+    assert lib.lg_sp_encode_split(fake, 1, 8192, 4096, arr, fake, 1 << 40, fake, fake, None) == _cabi.LG_ERR_INVALID and b"2^25" in lib.lg_last_error()
+    assert lib.lg_sp_pack_conv_weight_split(fake, 65, 64, 3, fake, None) == _cabi.LG_ERR_INVALID       # 3 x 3 layers: cout % 64
+    assert lib.lg_sp_pack_conv_weight_split(fake, 64, 48, 1, fake, None) == _cabi.LG_ERR_INVALID       # cin % 32
     # precision enum: every named mode is accepted; the removed split-bf16 value (3) and anything past the last one are not
     for name, val in _cabi.LG_PREC.items():
         cfg = _cabi.LgConfig(256, 256, 9, 4, 0, 0.95, 0.99, 0.1, -1, val, -1)
